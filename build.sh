@@ -1,0 +1,9 @@
+#!/bin/bash
+# Builds libsfm_fusion.so (gfx950 only) in-tree.  -ffp-contract=off: bit-exact IEEE double
+# evaluation order on device and host (see fusion_kernels.h).
+set -e
+cd "$(dirname "$0")"
+mkdir -p sfm_amd/lib build
+hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -Wall \
+  -save-temps=obj sfm_amd/csrc/fusion_capi.hip -o build/libsfm_fusion.so "$@"
+cp build/libsfm_fusion.so sfm_amd/lib/libsfm_fusion.so

@@ -1,0 +1,133 @@
+/*
+ * sfm_fusion.h -- C ABI of the MI355X dense-fusion library (libsfm_fusion.so).
+ *
+ * Drop-in boundary for ONE stage of CarterDiOrio/SfM: the dense fusion that the reference
+ * runs as
+ *     sfm::DenseReconstruction dense_reconstruction{map};      (src/reconstruct.cpp:72)
+ *     dense_reconstruction.reconstruct(dense_file);            (src/reconstruct.cpp:73)
+ * The reference has no plugin/FFI boundary of its own; this header is what a C++ facade
+ * with the reference's two-call shape (sfm_amd/cpp/dense_reconstruction.hpp) binds.
+ * Citations are relative to /root/reference/reconstruction.
+ *
+ * Conventions
+ *   - plain C types, no exceptions cross the ABI; every call returns an int status
+ *     (SFM_OK or a negative SFM_E_*), sfm_fusion_last_error() gives the text.
+ *   - 4x4 matrices are 16 doubles, COLUMN-major, i.e. Eigen::Matrix4d::data().
+ *   - images: depth = CV_16UC1 rows, colour = CV_8UC3 rows in B,G,R order, with a row
+ *     stride in bytes (cv::Mat::step).  The library COPIES pixels into its own HBM buffers
+ *     inside sfm_fusion_add_keyframe; the caller's buffers may be released on return.
+ *   - a ctx is driven by one host thread at a time; distinct ctxs are independent.
+ *   - all geometry is in RAW depth units, exactly like the reference.
+ */
+#ifndef SFM_FUSION_H
+#define SFM_FUSION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_OK 0
+#define SFM_E_INVALID (-1)     /* bad argument / bad call order */
+#define SFM_E_HIP (-2)         /* HIP runtime error (text in last_error) */
+#define SFM_E_TABLE_FULL (-3)  /* voxel table capacity exhausted */
+#define SFM_E_KEY_RANGE (-4)   /* a voxel index does not fit the packed 3x21-bit key */
+#define SFM_E_CAPACITY (-5)    /* accepted-point list capacity exhausted */
+#define SFM_E_UNSUPPORTED (-6) /* e.g. more than SFM_MAX_NEIGHBORS filtered neighbours */
+#define SFM_E_NOMEM (-7)
+
+#define SFM_MEM_HOST 0   /* pointers are host memory   */
+#define SFM_MEM_DEVICE 1 /* pointers are device memory on the ctx's GPU */
+
+#define SFM_MAX_NEIGHBORS 32 /* filtered neighbours per keyframe handled by the kernels */
+
+typedef struct sfm_fusion_ctx sfm_fusion_ctx;
+
+/* Fusion constants.  Defaults = the reference's compile-time values:
+ * include/reconstruction/dense_reconstruction.hpp:44-56, src/dense_reconstruction.cpp:23-25,
+ * :85 (0.30), :229 (0.50), :309 (1000). */
+typedef struct sfm_fusion_params {
+    double base_line;       /* 0.50 */
+    double T_cov;           /* 0.5  */
+    double voxel_size;      /* 0.05 */
+    double T_dist;          /* 0.50 */
+    double min_dist_filter; /* 0.0  */
+    double dir_dot;         /* 0.30 */
+    double S[3];            /* diag(0.05, 0.05, 10.0) */
+    double depth_div;       /* 1000 */
+    double close_frac;      /* 0.50 */
+    uint64_t table_capacity; /* voxel-table slots (rounded up to 2^n); 0 = size automatically */
+    uint64_t max_points;     /* accepted-point list capacity; 0 = size automatically */
+} sfm_fusion_params;
+
+/* The four progress counts the reference logs (src/dense_reconstruction.cpp:56-58,
+ * :118-120) plus traffic counters used for the roofline's algorithmic byte count. */
+typedef struct sfm_fusion_stats {
+    uint64_t n_frames;
+    uint64_t global_before; /* "Points before voxel removal" */
+    uint64_t global_after;  /* "Points after voxel removal"  */
+    uint64_t n_px;          /* pixels of all keyframes */
+    uint64_t n_gather;      /* neighbour depth reads (visible projections) */
+    uint64_t n_acc;         /* accepted pixels = sum of per-frame "before" counts */
+    uint64_t n_hit;         /* visibility-mask stores the reference performs */
+    uint64_t n_vox;         /* output points */
+    uint64_t table_capacity;
+    uint64_t table_used;
+    uint64_t max_probe;     /* longest probe sequence seen by an insert */
+    double last_run_ms;     /* device time of the last sfm_fusion_run (HIP events) */
+    double frame_kernels_ms;/* device time between first and last per-frame kernel */
+} sfm_fusion_stats;
+
+void sfm_fusion_default_params(sfm_fusion_params *p);
+
+/* Replaces `DenseReconstruction(sfm::Map&)` (dense_reconstruction.cpp:20-26).
+ * device = HIP device ordinal.  `stream` = a hipStream_t to run on, or NULL for a private one. */
+int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
+                      sfm_fusion_ctx **out);
+void sfm_fusion_destroy(sfm_fusion_ctx *ctx);
+
+/* One selected keyframe (reconstruct() selection rule :32-38 stays in the facade).
+ * order_idx = position in processing order (the reference iterates a std::set, :48);
+ * indices must be added as 0,1,2,... .  Reads what the reference reads through
+ * KeyFrame::img / get_depth_image() / camera_calibration() / transform() /
+ * world_to_camera() (src/keyframe.cpp:31-54).  K = {fx, fy, cx, cy}. */
+int sfm_fusion_add_keyframe(sfm_fusion_ctx *ctx, uint32_t order_idx, int32_t W, int32_t H,
+                            const uint16_t *depth, size_t depth_stride_bytes,
+                            const uint8_t *bgr, size_t bgr_stride_bytes,
+                            const double K[4], const double T_wk[16], const double T_kw[16],
+                            int mem_kind);
+
+/* Map::get_neighbors(kf, 100) (src/map.cpp:152-160) as order indices, in the order the
+ * reference would iterate them.  The distance/direction filter of process_frame
+ * (src/dense_reconstruction.cpp:72-89) is applied inside the library. */
+int sfm_fusion_set_neighbors(sfm_fusion_ctx *ctx, uint32_t order_idx,
+                             const uint32_t *nbr_order_idx, uint32_t n);
+
+/* Replaces the body of `reconstruct(std::ostream&)` up to the writer loop (:40-58):
+ * zeroes the visibility masks, fuses every keyframe in order, applies the per-frame and the
+ * global first-wins voxel filter.  May be called repeatedly (each call starts from clean
+ * masks); the result stays in HBM until the next run. */
+int sfm_fusion_run(sfm_fusion_ctx *ctx);
+
+int sfm_fusion_num_points(sfm_fusion_ctx *ctx, uint64_t *n);
+
+/* Copies the cloud to host arrays, sorted by voxel key (k0,k1,k2 unsigned lexicographic).
+ * xyz: N*3 doubles; bgr: N*3 int32 in B,G,R order (PointInfo::color); key: N*3 uint64
+ * (the reference's std::tuple<size_t,size_t,size_t>, :270-274); tag: N uint64 =
+ * (order_idx << 32) | (v*W + u) of the winning pixel.  Any pointer may be NULL. */
+int sfm_fusion_read_points(sfm_fusion_ctx *ctx, double *xyz, int32_t *bgr, uint64_t *key,
+                           uint64_t *tag);
+
+int sfm_fusion_get_stats(sfm_fusion_ctx *ctx, sfm_fusion_stats *out);
+/* per-frame "Points before/after voxel filter" (:118-120); arrays of n_frames. */
+int sfm_fusion_get_frame_counts(sfm_fusion_ctx *ctx, uint64_t *before, uint64_t *after);
+
+const char *sfm_fusion_last_error(sfm_fusion_ctx *ctx);
+const char *sfm_fusion_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFM_FUSION_H */

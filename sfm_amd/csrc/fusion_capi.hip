@@ -1,0 +1,551 @@
+// fusion_capi.hip -- host side of libsfm_fusion.so: the C ABI of include/sfm_fusion.h over
+// the gfx950 kernels in fusion_kernels.h.  No CPU fallback exists: every entry point that
+// computes needs a HIP device and fails with SFM_E_HIP otherwise.
+#include "../../include/sfm_fusion.h"
+#include "fusion_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace sfm;
+
+namespace {
+
+struct HostFrame {
+    int32_t W = 0, H = 0;
+    double K[4];
+    double Twk[16];  // column-major as given
+    double Tkw[16];
+    uint16_t *d_depth = nullptr;
+    uint8_t *d_bgr = nullptr;
+    std::vector<uint32_t> nbrs;  // raw Map::get_neighbors list
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    uint64_t n = 0;
+};
+
+}  // namespace
+
+struct sfm_fusion_ctx {
+    sfm_fusion_params prm;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<HostFrame> frames;
+    bool layout_dirty = true;
+
+    DevBuf<FrameDev> d_frames;
+    DevBuf<uint32_t> d_nbr;
+    DevBuf<uint8_t> d_masks;
+    DevBuf<Slot> d_table;
+    DevBuf<uint32_t> d_mark;
+    DevBuf<unsigned long long> d_list_key, d_list_tag, d_out_key, d_out_tag;
+    DevBuf<double> d_list_xyz, d_out_xyz;
+    DevBuf<uint32_t> d_list_bgr, d_out_bgr;
+    DevBuf<unsigned long long> d_fbefore, d_fafter;
+    Counters *d_ctr = nullptr;
+    Counters *h_ctr = nullptr;  // pinned
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    uint64_t total_px = 0;
+    uint64_t n_out = 0;
+    bool have_result = false;
+    sfm_fusion_stats stats;
+    std::vector<uint64_t> fbefore, fafter;
+    std::string err;
+};
+
+namespace {
+
+int fail(sfm_fusion_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail((c), e_ == hipErrorOutOfMemory ? SFM_E_NOMEM : SFM_E_HIP,            \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+template <typename T>
+int ensure(sfm_fusion_ctx *c, DevBuf<T> &b, uint64_t n)
+{
+    if (b.n >= n && b.p) return SFM_OK;
+    if (b.p) HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.n = 0;
+    HIP_TRY(c, hipMalloc(&b.p, std::max<uint64_t>(n, 1) * sizeof(T)));
+    b.n = n;
+    return SFM_OK;
+}
+
+template <typename T>
+void release(DevBuf<T> &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.n = 0;
+}
+
+uint64_t pow2_at_least(uint64_t n)
+{
+    uint64_t c = 1024;
+    while (c < n) c <<= 1;
+    return c;
+}
+
+// smallest s with sqrt(s) >= T  ("(p - p_w).norm() < T_dist", dense_reconstruction.cpp:224,
+// evaluated on the squared norm so the kernel needs no sqrt).
+double sqrt_threshold(double T)
+{
+    if (!(T > 0)) return 0.0;  // sqrt(s) >= 0 >= T for every s; NaN T: never "<"
+    if (std::isinf(T)) return T;
+    double s = T * T;
+    while (std::sqrt(s) >= T && s > 0) s = std::nextafter(s, 0.0);
+    while (std::sqrt(s) < T) s = std::nextafter(s, std::numeric_limits<double>::infinity());
+    return s;
+}
+
+// dense_reconstruction.cpp:72-89: keep neighbour lf of frame f?
+// norm(): (dx^2 + dy^2) + dz^2; R*(0,0,1): third column; dot: (a0b0 + a1b1) + a2b2.
+bool neighbor_kept(const sfm_fusion_params &p, const HostFrame &f, const HostFrame &lf)
+{
+    const double dx = lf.Twk[12] - f.Twk[12];
+    const double dy = lf.Twk[13] - f.Twk[13];
+    const double dz = lf.Twk[14] - f.Twk[14];
+    const double n = std::sqrt((dx * dx + dy * dy) + dz * dz);
+    if (n > p.min_dist_filter) return true;
+    const double dot = (f.Twk[8] * lf.Twk[8] + f.Twk[9] * lf.Twk[9]) + f.Twk[10] * lf.Twk[10];
+    return dot < p.dir_dot;
+}
+
+void rows3(const double cm[16], double out[12])
+{
+    for (int r = 0; r < 3; r++)
+        for (int col = 0; col < 4; col++) out[r * 4 + col] = cm[r + 4 * col];
+}
+
+int build_layout(sfm_fusion_ctx *c)
+{
+    const size_t n = c->frames.size();
+    uint64_t total = 0;
+    std::vector<uint64_t> moff(n);
+    for (size_t i = 0; i < n; i++) {
+        moff[i] = total;
+        total += ((uint64_t)c->frames[i].W * c->frames[i].H + 255) / 256 * 256;
+    }
+    c->total_px = 0;
+    for (auto &f : c->frames) c->total_px += (uint64_t)f.W * f.H;
+    int rc;
+    if ((rc = ensure(c, c->d_masks, total))) return rc;
+    std::vector<FrameDev> fd(n);
+    std::vector<uint32_t> nbr;
+    for (size_t i = 0; i < n; i++) {
+        const HostFrame &f = c->frames[i];
+        FrameDev &d = fd[i];
+        std::memcpy(d.K, f.K, sizeof d.K);
+        rows3(f.Twk, d.Twk);
+        rows3(f.Tkw, d.Tkw);
+        d.depth = f.d_depth;
+        d.bgr = f.d_bgr;
+        d.mask = c->d_masks.p + moff[i];
+        d.W = f.W;
+        d.H = f.H;
+        d.nbr_begin = (uint32_t)nbr.size();
+        for (uint32_t j : f.nbrs)
+            if (neighbor_kept(c->prm, f, c->frames[j])) nbr.push_back(j);
+        d.nbr_count = (uint32_t)nbr.size() - d.nbr_begin;
+        d.order = (uint32_t)i;
+        d.pad = 0;
+        if (d.nbr_count > SFM_MAX_NEIGHBORS)
+            return fail(c, SFM_E_UNSUPPORTED,
+                        "keyframe " + std::to_string(i) + " has " + std::to_string(d.nbr_count) +
+                            " filtered neighbours; the kernels handle at most " +
+                            std::to_string(SFM_MAX_NEIGHBORS));
+    }
+    if ((rc = ensure(c, c->d_frames, n))) return rc;
+    if ((rc = ensure(c, c->d_nbr, nbr.size()))) return rc;
+    if ((rc = ensure(c, c->d_fbefore, n))) return rc;
+    if ((rc = ensure(c, c->d_fafter, n))) return rc;
+    if (n) HIP_TRY(c, hipMemcpy(c->d_frames.p, fd.data(), n * sizeof(FrameDev), hipMemcpyHostToDevice));
+    if (!nbr.empty())
+        HIP_TRY(c, hipMemcpy(c->d_nbr.p, nbr.data(), nbr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->layout_dirty = false;
+    return SFM_OK;
+}
+
+int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t list_cap, uint32_t *err_bits)
+{
+    const size_t n = c->frames.size();
+    int rc;
+    if ((rc = ensure(c, c->d_table, table_cap))) return rc;
+    if ((rc = ensure(c, c->d_mark, table_cap))) return rc;
+    if ((rc = ensure(c, c->d_list_key, list_cap))) return rc;
+    if ((rc = ensure(c, c->d_list_tag, list_cap))) return rc;
+    if ((rc = ensure(c, c->d_list_xyz, 3 * list_cap))) return rc;
+    if ((rc = ensure(c, c->d_list_bgr, list_cap))) return rc;
+    table_cap = pow2_at_least(table_cap);
+    // a previous run may have left bigger buffers; use exactly table_cap slots (power of 2)
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    if (c->d_masks.n) HIP_TRY(c, hipMemsetAsync(c->d_masks.p, 0, c->d_masks.n, s));  // :40-45
+    HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0xFF, table_cap * sizeof(Slot), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_mark.p, 0, table_cap * sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), s));
+    if (n) {
+        HIP_TRY(c, hipMemsetAsync(c->d_fbefore.p, 0, n * sizeof(unsigned long long), s));
+        HIP_TRY(c, hipMemsetAsync(c->d_fafter.p, 0, n * sizeof(unsigned long long), s));
+    }
+    FuseArgs a;
+    a.table = c->d_table.p;
+    a.mark = c->d_mark.p;
+    a.table_mask = table_cap - 1;
+    a.list_key = c->d_list_key.p;
+    a.list_tag = c->d_list_tag.p;
+    a.list_xyz = c->d_list_xyz.p;
+    a.list_bgr = c->d_list_bgr.p;
+    a.list_cap = list_cap;
+    a.ctr = c->d_ctr;
+    a.frame_before = c->d_fbefore.p;
+    a.frame_after = c->d_fafter.p;
+    a.P.base_line = c->prm.base_line;
+    a.P.T_cov = c->prm.T_cov;
+    a.P.voxel_size = c->prm.voxel_size;
+    a.P.tau_dist2 = sqrt_threshold(c->prm.T_dist);
+    a.P.S0 = c->prm.S[0];
+    a.P.S1 = c->prm.S[1];
+    a.P.S2 = c->prm.S[2];
+    a.P.depth_div = c->prm.depth_div;
+    a.P.close_frac = c->prm.close_frac;
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    for (size_t i = 0; i < n; i++) {  // :48-52, strictly in order
+        const uint64_t px = (uint64_t)c->frames[i].W * c->frames[i].H;
+        if (px == 0) continue;
+        const uint32_t tiles = (uint32_t)((px + kTile - 1) / kTile);
+        a.f = (uint32_t)i;
+        hipLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(kWave), 0, s,
+                           (const FrameDev *)c->d_frames.p, (const uint32_t *)c->d_nbr.p, a);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *err_bits = c->h_ctr->err;
+    if (*err_bits) return SFM_OK;  // caller decides: grow and retry, or report
+    const uint64_t n_list = c->h_ctr->list_count;
+    if ((rc = ensure(c, c->d_out_key, n_list))) return rc;
+    if ((rc = ensure(c, c->d_out_tag, n_list))) return rc;
+    if ((rc = ensure(c, c->d_out_xyz, 3 * n_list))) return rc;
+    if ((rc = ensure(c, c->d_out_bgr, n_list))) return rc;
+    if (n_list) {
+        FinalizeArgs fa;
+        fa.table = c->d_table.p;
+        fa.table_mask = table_cap - 1;
+        fa.list_key = c->d_list_key.p;
+        fa.list_tag = c->d_list_tag.p;
+        fa.list_xyz = c->d_list_xyz.p;
+        fa.list_bgr = c->d_list_bgr.p;
+        fa.n_list = n_list;
+        fa.ctr = c->d_ctr;
+        fa.out_xyz = c->d_out_xyz.p;
+        fa.out_bgr = c->d_out_bgr.p;
+        fa.out_key = c->d_out_key.p;
+        fa.out_tag = c->d_out_tag.p;
+        const uint64_t blocks = std::min<uint64_t>((n_list + 255) / 256, 2048);
+        hipLaunchKernelGGL(finalize_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, fa);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return SFM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void sfm_fusion_default_params(sfm_fusion_params *p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->base_line = 0.50;
+    p->T_cov = 0.5;
+    p->voxel_size = 0.05;
+    p->T_dist = 0.50;
+    p->min_dist_filter = 0.0;
+    p->dir_dot = 0.30;
+    p->S[0] = 0.05;
+    p->S[1] = 0.05;
+    p->S[2] = 10.0;
+    p->depth_div = 1000.0;
+    p->close_frac = 0.50;
+    p->table_capacity = 0;
+    p->max_points = 0;
+}
+
+int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream, sfm_fusion_ctx **out)
+{
+    if (!out) return SFM_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SFM_E_HIP;
+    sfm_fusion_ctx *c = new (std::nothrow) sfm_fusion_ctx();
+    if (!c) return SFM_E_NOMEM;
+    if (params) c->prm = *params; else sfm_fusion_default_params(&c->prm);
+    c->device = device;
+    std::memset(&c->stats, 0, sizeof c->stats);
+    bool ok = hipSetDevice(device) == hipSuccess;
+    if (ok && stream) {
+        c->stream = (hipStream_t)stream;
+    } else if (ok) {
+        ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+        c->own_stream = ok;
+    }
+    ok = ok && hipMalloc(&c->d_ctr, sizeof(Counters)) == hipSuccess;
+    ok = ok && hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    if (!ok) {
+        sfm_fusion_destroy(c);
+        return SFM_E_HIP;
+    }
+    *out = c;
+    return SFM_OK;
+}
+
+void sfm_fusion_destroy(sfm_fusion_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &f : c->frames) {
+        if (f.d_depth) (void)hipFree(f.d_depth);
+        if (f.d_bgr) (void)hipFree(f.d_bgr);
+    }
+    release(c->d_frames); release(c->d_nbr); release(c->d_masks); release(c->d_table);
+    release(c->d_mark); release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
+    release(c->d_out_tag); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
+    release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter);
+    if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int sfm_fusion_add_keyframe(sfm_fusion_ctx *c, uint32_t order_idx, int32_t W, int32_t H,
+                            const uint16_t *depth, size_t depth_stride, const uint8_t *bgr,
+                            size_t bgr_stride, const double K[4], const double T_wk[16],
+                            const double T_kw[16], int mem_kind)
+{
+    if (!c) return SFM_E_INVALID;
+    if (order_idx != c->frames.size())
+        return fail(c, SFM_E_INVALID, "keyframes must be added in order 0,1,2,...");
+    if (W < 0 || H < 0 || !K || !T_wk || !T_kw) return fail(c, SFM_E_INVALID, "bad keyframe argument");
+    if ((uint64_t)W * (uint64_t)H > 0xFFFFFFFFull) return fail(c, SFM_E_INVALID, "image too large");
+    const uint64_t px = (uint64_t)W * H;
+    if (px && (!depth || !bgr)) return fail(c, SFM_E_INVALID, "null image pointer");
+    if (px && (depth_stride < 2ull * W || bgr_stride < 3ull * W))
+        return fail(c, SFM_E_INVALID, "row stride smaller than a row");
+    if (mem_kind != SFM_MEM_HOST && mem_kind != SFM_MEM_DEVICE) return fail(c, SFM_E_INVALID, "bad mem_kind");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HostFrame f;
+    f.W = W;
+    f.H = H;
+    std::memcpy(f.K, K, sizeof f.K);
+    std::memcpy(f.Twk, T_wk, sizeof f.Twk);
+    std::memcpy(f.Tkw, T_kw, sizeof f.Tkw);
+    if (px) {
+        // +8 bytes of slack: the kernel reads depth as ushort4 / colour per byte
+        HIP_TRY(c, hipMalloc(&f.d_depth, px * 2 + 8));
+        hipError_t e = hipMalloc(&f.d_bgr, px * 3 + 8);
+        if (e != hipSuccess) {
+            (void)hipFree(f.d_depth);
+            return fail(c, SFM_E_NOMEM, "hipMalloc colour");
+        }
+        const hipMemcpyKind kind = mem_kind == SFM_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+        hipError_t e1 = hipMemcpy2D(f.d_depth, 2ull * W, depth, depth_stride, 2ull * W, H, kind);
+        hipError_t e2 = hipMemcpy2D(f.d_bgr, 3ull * W, bgr, bgr_stride, 3ull * W, H, kind);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            (void)hipFree(f.d_depth);
+            (void)hipFree(f.d_bgr);
+            return fail(c, SFM_E_HIP, std::string("hipMemcpy2D: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        }
+    }
+    c->frames.push_back(std::move(f));
+    c->layout_dirty = true;
+    c->have_result = false;
+    return SFM_OK;
+}
+
+int sfm_fusion_set_neighbors(sfm_fusion_ctx *c, uint32_t order_idx, const uint32_t *nbr, uint32_t n)
+{
+    if (!c) return SFM_E_INVALID;
+    if (order_idx >= c->frames.size()) return fail(c, SFM_E_INVALID, "unknown keyframe");
+    if (n && !nbr) return fail(c, SFM_E_INVALID, "null neighbour list");
+    c->frames[order_idx].nbrs.assign(nbr, nbr + n);
+    c->layout_dirty = true;
+    c->have_result = false;
+    return SFM_OK;
+}
+
+int sfm_fusion_run(sfm_fusion_ctx *c)
+{
+    if (!c) return SFM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = c->frames.size();
+    for (size_t i = 0; i < n; i++)
+        for (uint32_t j : c->frames[i].nbrs) {
+            if (j >= n) return fail(c, SFM_E_INVALID, "neighbour index out of range");
+            if (j == i) return fail(c, SFM_E_INVALID, "a keyframe cannot be its own neighbour");
+        }
+    int rc;
+    if (c->layout_dirty && (rc = build_layout(c))) return rc;
+    c->have_result = false;
+    const bool fixed_tab = c->prm.table_capacity != 0, fixed_list = c->prm.max_points != 0;
+    uint64_t list_cap = fixed_list ? c->prm.max_points
+                                   : std::max<uint64_t>(c->d_list_key.n, std::max<uint64_t>(c->total_px / 4, 1 << 16));
+    uint64_t table_cap = fixed_tab ? pow2_at_least(c->prm.table_capacity)
+                                   : std::max<uint64_t>(pow2_at_least(c->d_table.n ? c->d_table.n : 0),
+                                                        pow2_at_least(std::max<uint64_t>(c->total_px / 2, 1 << 16)));
+    for (int attempt = 0;; attempt++) {
+        uint32_t err = 0;
+        if ((rc = run_once(c, table_cap, list_cap, &err))) return rc;
+        if (!err) break;
+        if (err & kErrKeyRange)
+            return fail(c, SFM_E_KEY_RANGE,
+                        "a fused point's voxel index is outside the packed key range of +-(2^20-1) per axis");
+        bool grown = false;
+        if ((err & kErrListFull) && !fixed_list && list_cap < c->total_px) {
+            list_cap = std::min<uint64_t>(c->total_px, std::max<uint64_t>(list_cap * 2, c->h_ctr->list_count));
+            grown = true;
+        }
+        if ((err & kErrTableFull) && !fixed_tab && attempt < 8) {
+            table_cap *= 2;
+            grown = true;
+        }
+        if (!grown) {
+            if (err & kErrListFull) return fail(c, SFM_E_CAPACITY, "accepted-point list capacity (max_points) exhausted");
+            return fail(c, SFM_E_TABLE_FULL, "voxel table capacity exhausted");
+        }
+    }
+    // keep the table under half full so probe sequences stay short on the next run
+    c->n_out = c->h_ctr->out_count;
+    sfm_fusion_stats &st = c->stats;
+    std::memset(&st, 0, sizeof st);
+    st.n_frames = n;
+    st.n_px = c->total_px;
+    st.n_gather = c->h_ctr->n_gather;
+    st.n_hit = c->h_ctr->n_hit;
+    st.n_vox = c->n_out;
+    st.global_after = c->n_out;
+    st.table_capacity = pow2_at_least(table_cap);
+    st.table_used = c->h_ctr->table_used;
+    st.max_probe = c->h_ctr->max_probe;
+    c->fbefore.assign(n, 0);
+    c->fafter.assign(n, 0);
+    if (n) {
+        HIP_TRY(c, hipMemcpy(c->fbefore.data(), c->d_fbefore.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->fafter.data(), c->d_fafter.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    st.n_acc = std::accumulate(c->fbefore.begin(), c->fbefore.end(), (uint64_t)0);
+    st.global_before = std::accumulate(c->fafter.begin(), c->fafter.end(), (uint64_t)0);
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[3]));
+    st.last_run_ms = ms;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+    st.frame_kernels_ms = ms;
+    c->have_result = true;
+    return SFM_OK;
+}
+
+int sfm_fusion_num_points(sfm_fusion_ctx *c, uint64_t *n)
+{
+    if (!c || !n) return SFM_E_INVALID;
+    if (!c->have_result) return fail(c, SFM_E_INVALID, "no result: call sfm_fusion_run first");
+    *n = c->n_out;
+    return SFM_OK;
+}
+
+static inline uint64_t unpack_axis(uint64_t code)
+{
+    if (code == 0x100000ull) return 0x8000000000000000ull;
+    int64_t k = (int64_t)(code << 43) >> 43;  // sign-extend 21 bits
+    return (uint64_t)k;
+}
+
+int sfm_fusion_read_points(sfm_fusion_ctx *c, double *xyz, int32_t *bgr, uint64_t *key, uint64_t *tag)
+{
+    if (!c) return SFM_E_INVALID;
+    if (!c->have_result) return fail(c, SFM_E_INVALID, "no result: call sfm_fusion_run first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t n = c->n_out;
+    if (n == 0) return SFM_OK;
+    std::vector<unsigned long long> hk(n), ht(n);
+    std::vector<double> hx(3 * n);
+    std::vector<uint32_t> hc(n);
+    HIP_TRY(c, hipMemcpy(hk.data(), c->d_out_key.p, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(ht.data(), c->d_out_tag.p, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(hx.data(), c->d_out_xyz.p, n * 24, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(hc.data(), c->d_out_bgr.p, n * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> k0(n), k1(n), k2(n);
+    for (uint64_t i = 0; i < n; i++) {
+        k0[i] = unpack_axis((hk[i] >> 42) & 0x1FFFFF);
+        k1[i] = unpack_axis((hk[i] >> 21) & 0x1FFFFF);
+        k2[i] = unpack_axis(hk[i] & 0x1FFFFF);
+    }
+    std::vector<uint64_t> order(n);
+    std::iota(order.begin(), order.end(), (uint64_t)0);
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+        if (k0[a] != k0[b]) return k0[a] < k0[b];
+        if (k1[a] != k1[b]) return k1[a] < k1[b];
+        return k2[a] < k2[b];
+    });
+    for (uint64_t o = 0; o < n; o++) {
+        const uint64_t i = order[o];
+        if (xyz) { xyz[3 * o] = hx[3 * i]; xyz[3 * o + 1] = hx[3 * i + 1]; xyz[3 * o + 2] = hx[3 * i + 2]; }
+        if (bgr) { bgr[3 * o] = hc[i] & 255; bgr[3 * o + 1] = (hc[i] >> 8) & 255; bgr[3 * o + 2] = (hc[i] >> 16) & 255; }
+        if (key) { key[3 * o] = k0[i]; key[3 * o + 1] = k1[i]; key[3 * o + 2] = k2[i]; }
+        if (tag) tag[o] = ht[i];
+    }
+    return SFM_OK;
+}
+
+int sfm_fusion_get_stats(sfm_fusion_ctx *c, sfm_fusion_stats *out)
+{
+    if (!c || !out) return SFM_E_INVALID;
+    if (!c->have_result) return fail(c, SFM_E_INVALID, "no result: call sfm_fusion_run first");
+    *out = c->stats;
+    return SFM_OK;
+}
+
+int sfm_fusion_get_frame_counts(sfm_fusion_ctx *c, uint64_t *before, uint64_t *after)
+{
+    if (!c) return SFM_E_INVALID;
+    if (!c->have_result) return fail(c, SFM_E_INVALID, "no result: call sfm_fusion_run first");
+    const size_t n = c->frames.size();
+    if (before) std::copy(c->fbefore.begin(), c->fbefore.end(), before);
+    if (after) std::copy(c->fafter.begin(), c->fafter.end(), after);
+    (void)n;
+    return SFM_OK;
+}
+
+const char *sfm_fusion_last_error(sfm_fusion_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+
+const char *sfm_fusion_version(void) { return "sfm_fusion 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,328 @@
+"""ctypes binding of libsfm_fusion.so (include/sfm_fusion.h) and a host-side mirror of the
+reference's dense-reconstruction interface.
+
+Reference interface mirrored here (paths relative to /root/reference/reconstruction):
+  * `DenseReconstruction(sfm::Map&)` / `reconstruct(std::ostream&)`
+    (include/reconstruction/dense_reconstruction.hpp:26-31, src/dense_reconstruction.cpp:29-65)
+  * the containers it reads: `Map::covisibility_edge`, `Map::get_neighbors`
+    (include/reconstruction/map.hpp:143, src/map.cpp:152-160) and the KeyFrame accessors
+    `img`, `get_depth_image()`, `camera_calibration()`, `transform()`, `world_to_camera()`
+    (src/keyframe.cpp:31-54).
+
+There is NO CPU fallback: loading fails loudly if the HIP library has not been built, and
+every compute call needs a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsfm_fusion.so")
+
+SFM_OK = 0
+SFM_E_INVALID, SFM_E_HIP, SFM_E_TABLE_FULL, SFM_E_KEY_RANGE = -1, -2, -3, -4
+SFM_E_CAPACITY, SFM_E_UNSUPPORTED, SFM_E_NOMEM = -5, -6, -7
+SFM_MEM_HOST, SFM_MEM_DEVICE = 0, 1
+SFM_MAX_NEIGHBORS = 32
+
+EXPORTS = [
+    "sfm_fusion_default_params", "sfm_fusion_create", "sfm_fusion_destroy",
+    "sfm_fusion_add_keyframe", "sfm_fusion_set_neighbors", "sfm_fusion_run",
+    "sfm_fusion_num_points", "sfm_fusion_read_points", "sfm_fusion_get_stats",
+    "sfm_fusion_get_frame_counts", "sfm_fusion_last_error", "sfm_fusion_version",
+]
+
+
+class FusionParams(C.Structure):
+    """sfm_fusion_params; defaults = dense_reconstruction.hpp:44-56."""
+    _fields_ = [
+        ("base_line", C.c_double), ("T_cov", C.c_double), ("voxel_size", C.c_double),
+        ("T_dist", C.c_double), ("min_dist_filter", C.c_double), ("dir_dot", C.c_double),
+        ("S", C.c_double * 3), ("depth_div", C.c_double), ("close_frac", C.c_double),
+        ("table_capacity", C.c_uint64), ("max_points", C.c_uint64),
+    ]
+
+
+class FusionStats(C.Structure):
+    _fields_ = [
+        ("n_frames", C.c_uint64), ("global_before", C.c_uint64), ("global_after", C.c_uint64),
+        ("n_px", C.c_uint64), ("n_gather", C.c_uint64), ("n_acc", C.c_uint64),
+        ("n_hit", C.c_uint64), ("n_vox", C.c_uint64), ("table_capacity", C.c_uint64),
+        ("table_used", C.c_uint64), ("max_probe", C.c_uint64),
+        ("last_run_ms", C.c_double), ("frame_kernels_ms", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class FusionError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sfm_fusion error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the HIP library; raises if it was not built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run ./build.sh (hipcc --offload-arch=gfx950). "
+                          "sfm_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    dp = C.POINTER(C.c_double)
+    L.sfm_fusion_default_params.argtypes = [C.POINTER(FusionParams)]
+    L.sfm_fusion_default_params.restype = None
+    L.sfm_fusion_create.argtypes = [C.POINTER(FusionParams), C.c_int, vp, C.POINTER(vp)]
+    L.sfm_fusion_destroy.argtypes = [vp]
+    L.sfm_fusion_destroy.restype = None
+    L.sfm_fusion_add_keyframe.argtypes = [vp, u32, i32, i32, vp, C.c_size_t, vp, C.c_size_t, dp, dp, dp, C.c_int]
+    L.sfm_fusion_set_neighbors.argtypes = [vp, u32, C.POINTER(u32), u32]
+    L.sfm_fusion_run.argtypes = [vp]
+    L.sfm_fusion_num_points.argtypes = [vp, C.POINTER(u64)]
+    L.sfm_fusion_read_points.argtypes = [vp, vp, vp, vp, vp]
+    L.sfm_fusion_get_stats.argtypes = [vp, C.POINTER(FusionStats)]
+    L.sfm_fusion_get_frame_counts.argtypes = [vp, vp, vp]
+    L.sfm_fusion_last_error.argtypes = [vp]
+    L.sfm_fusion_last_error.restype = C.c_char_p
+    L.sfm_fusion_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def default_params(**over) -> FusionParams:
+    p = FusionParams()
+    load_library().sfm_fusion_default_params(C.byref(p))
+    for k, v in over.items():
+        if k == "S":
+            p.S[0], p.S[1], p.S[2] = v
+        else:
+            if not hasattr(p, k):
+                raise KeyError(k)
+            setattr(p, k, v)
+    return p
+
+
+def _colmajor16(T):
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4).T).ravel()
+
+
+class FusionContext:
+    """Thin owner of one sfm_fusion_ctx."""
+
+    def __init__(self, params: FusionParams | None = None, device: int = 0, stream: int | None = None):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        p = params if params is not None else default_params()
+        rc = self._L.sfm_fusion_create(C.byref(p), int(device), C.c_void_p(stream or 0), C.byref(self._h))
+        if rc != SFM_OK:
+            raise FusionError(rc, "sfm_fusion_create failed (is a HIP device present?)")
+        self.n_frames = 0
+
+    def _check(self, rc):
+        if rc != SFM_OK:
+            raise FusionError(rc, self._L.sfm_fusion_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.sfm_fusion_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_keyframe(self, depth, bgr, K, T_wk, T_kw):
+        """depth (H,W) uint16, bgr (H,W,3) uint8 numpy arrays (rows may be strided)."""
+        depth = np.asarray(depth)
+        bgr = np.asarray(bgr)
+        if depth.dtype != np.uint16 or bgr.dtype != np.uint8:
+            raise TypeError("depth must be uint16 and bgr uint8")
+        H, W = depth.shape
+        if bgr.shape != (H, W, 3):
+            raise ValueError("bgr shape must be (H, W, 3)")
+        if W and depth.strides[1] != 2:
+            depth = np.ascontiguousarray(depth)
+        if W and (bgr.strides[2] != 1 or bgr.strides[1] != 3):
+            bgr = np.ascontiguousarray(bgr)
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        a, b = _colmajor16(T_wk), _colmajor16(T_kw)
+        dp = C.POINTER(C.c_double)
+        self._check(self._L.sfm_fusion_add_keyframe(
+            self._h, self.n_frames, W, H, depth.ctypes.data, depth.strides[0] if H else 2 * W,
+            bgr.ctypes.data, bgr.strides[0] if H else 3 * W,
+            Kc.ctypes.data_as(dp), a.ctypes.data_as(dp), b.ctypes.data_as(dp), SFM_MEM_HOST))
+        self.n_frames += 1
+        return self.n_frames - 1
+
+    def add_keyframe_device(self, depth_ptr, bgr_ptr, W, H, K, T_wk, T_kw, depth_stride=None, bgr_stride=None):
+        """Device-resident images (raw device pointers, e.g. torch.Tensor.data_ptr())."""
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        a, b = _colmajor16(T_wk), _colmajor16(T_kw)
+        dp = C.POINTER(C.c_double)
+        self._check(self._L.sfm_fusion_add_keyframe(
+            self._h, self.n_frames, W, H, C.c_void_p(depth_ptr), depth_stride or 2 * W,
+            C.c_void_p(bgr_ptr), bgr_stride or 3 * W,
+            Kc.ctypes.data_as(dp), a.ctypes.data_as(dp), b.ctypes.data_as(dp), SFM_MEM_DEVICE))
+        self.n_frames += 1
+        return self.n_frames - 1
+
+    def set_neighbors(self, idx, nbrs):
+        nb = np.ascontiguousarray(nbrs, dtype=np.uint32)
+        self._check(self._L.sfm_fusion_set_neighbors(
+            self._h, int(idx), nb.ctypes.data_as(C.POINTER(C.c_uint32)), nb.size))
+
+    def run(self):
+        self._check(self._L.sfm_fusion_run(self._h))
+
+    def num_points(self) -> int:
+        n = C.c_uint64()
+        self._check(self._L.sfm_fusion_num_points(self._h, C.byref(n)))
+        return n.value
+
+    def read_points(self):
+        n = self.num_points()
+        xyz = np.empty((n, 3), dtype=np.float64)
+        bgr = np.empty((n, 3), dtype=np.int32)
+        key = np.empty((n, 3), dtype=np.uint64)
+        tag = np.empty((n,), dtype=np.uint64)
+        self._check(self._L.sfm_fusion_read_points(self._h, xyz.ctypes.data, bgr.ctypes.data,
+                                                   key.ctypes.data, tag.ctypes.data))
+        return xyz, bgr, key, tag
+
+    def stats(self) -> dict:
+        st = FusionStats()
+        self._check(self._L.sfm_fusion_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def frame_counts(self):
+        before = np.zeros(self.n_frames, dtype=np.uint64)
+        after = np.zeros(self.n_frames, dtype=np.uint64)
+        self._check(self._L.sfm_fusion_get_frame_counts(self._h, before.ctypes.data, after.ctypes.data))
+        return before, after
+
+
+# ---- host-side mirror of the reference containers ------------------------------------------
+
+
+@dataclass(eq=False)
+class KeyFrame:
+    """The part of sfm::KeyFrame the fusion reads (src/keyframe.cpp:31-54)."""
+    img: np.ndarray            # (H,W,3) uint8 BGR  -- KeyFrame::img
+    depth_img: np.ndarray      # (H,W) uint16       -- get_depth_image()
+    K: tuple                   # fx,fy,cx,cy        -- camera_calibration()
+    T_wk: np.ndarray           # 4x4 camera->world  -- transform()
+    T_kw: np.ndarray           # 4x4 world->camera  -- world_to_camera()
+
+    def get_depth_image(self):
+        return self.depth_img
+
+    def camera_calibration(self):
+        return self.K
+
+    def transform(self):
+        return self.T_wk
+
+    def world_to_camera(self):
+        return self.T_kw
+
+
+@dataclass
+class Map:
+    """The part of sfm::Map the fusion reads: keyframes in insertion order, the covisibility
+    edge counts (map.hpp:143) and get_neighbors (map.cpp:152-160)."""
+    keyframes: list = field(default_factory=list)
+    covisibility_edge: dict = field(default_factory=dict)   # (i, j) with i<j -> shared count
+    _adj: dict = field(default_factory=dict)
+
+    def add_keyframe(self, kf: KeyFrame) -> int:
+        self.keyframes.append(kf)
+        return len(self.keyframes) - 1
+
+    def insert_edge(self, i: int, j: int, count: int):
+        """covisibility_insert (map.cpp:108-119): the count is frozen at first insertion."""
+        if i == j:
+            return
+        e = (min(i, j), max(i, j))
+        if e in self.covisibility_edge:
+            return
+        self.covisibility_edge[e] = int(count)
+        self._adj.setdefault(i, []).append(j)
+        self._adj.setdefault(j, []).append(i)
+
+    def get_edge(self, i, j) -> int:
+        return self.covisibility_edge[(min(i, j), max(i, j))]
+
+    def get_neighbors(self, i: int, min_shared_features: int = 15):
+        """Strictly more than min_shared_features (map.cpp:157).  Canonical order: ascending
+        keyframe index."""
+        return sorted(j for j in self._adj.get(i, []) if self.get_edge(i, j) > min_shared_features)
+
+
+class DenseReconstruction:
+    """Same two-call shape as sfm::DenseReconstruction.
+
+    reconstruct(os) selects every keyframe that is an endpoint of an edge with count >= 100
+    (dense_reconstruction.cpp:32-38), processes them in keyframe-insertion order, and writes
+    `x y z R G B` lines (:61-64) sorted by voxel key.
+    """
+    SELECT_MIN = 100    # dense_reconstruction.cpp:34
+    NEIGHBOR_MIN = 100  # dense_reconstruction.cpp:70
+
+    def __init__(self, map_: Map, params: FusionParams | None = None, device: int = 0):
+        self.map = map_
+        self.params = params
+        self.device = device
+        self.ctx = None
+        self.selected = []
+
+    def _select(self):
+        sel = set()
+        for (i, j), count in self.map.covisibility_edge.items():
+            if count >= self.SELECT_MIN:
+                sel.add(i)
+                sel.add(j)
+        return sorted(sel)
+
+    def fuse(self):
+        """Runs the GPU fusion; returns (xyz, bgr, key, tag) sorted by key.  Tags carry the
+        position in the selected-keyframe order."""
+        self.selected = self._select()
+        pos = {k: n for n, k in enumerate(self.selected)}
+        self.ctx = FusionContext(self.params, self.device)
+        for k in self.selected:
+            kf = self.map.keyframes[k]
+            self.ctx.add_keyframe(kf.get_depth_image(), kf.img, kf.camera_calibration(),
+                                  kf.transform(), kf.world_to_camera())
+        for k in self.selected:
+            nb = [pos[j] for j in self.map.get_neighbors(k, self.NEIGHBOR_MIN)]
+            self.ctx.set_neighbors(pos[k], nb)
+        self.ctx.run()
+        return self.ctx.read_points()
+
+    def reconstruct(self, os):
+        xyz, bgr, _, _ = self.fuse()
+        write_cloud(os, xyz, bgr)
+
+
+def format_double(x: float) -> str:
+    """`os << double` with default precision(6), floatfield unset == printf("%g")."""
+    return "%g" % x
+
+
+def write_cloud(os, xyz, bgr):
+    """dense_reconstruction.cpp:61-64: x y z then colour z,y,x (= R G B)."""
+    for p, c in zip(xyz, bgr):
+        os.write(f"{format_double(p[0])} {format_double(p[1])} {format_double(p[2])} "
+                 f"{int(c[2])} {int(c[1])} {int(c[0])}\n")

@@ -1,0 +1,51 @@
+"""Shared helpers for the parity tests: run the HIP path through the C ABI and compare it
+with the CPU oracle (bit-exact for keys/tags/colours/counts AND coordinates)."""
+import numpy as np
+
+from oracle import oracle
+from sfm_amd import fusion
+
+PARAM_KEYS = ("base_line", "T_cov", "voxel_size", "T_dist", "min_dist_filter", "dir_dot",
+              "depth_div", "close_frac", "S")
+
+
+def both_params(**over):
+    o = {k: v for k, v in over.items() if k in PARAM_KEYS}
+    return oracle.default_params(**o), fusion.default_params(**over)
+
+
+def run_gpu(frames, gparams, device=0):
+    ctx = fusion.FusionContext(gparams, device)
+    for f in frames:
+        ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+    for i, f in enumerate(frames):
+        ctx.set_neighbors(i, f.get("nbrs", []))
+    ctx.run()
+    xyz, bgr, key, tag = ctx.read_points()
+    st = ctx.stats()
+    fb, fa = ctx.frame_counts()
+    ctx.close()
+    return dict(xyz=xyz, bgr=bgr, key=key, tag=tag, stats=st, frame_before=fb, frame_after=fa)
+
+
+def assert_same_cloud(g, c, exact_xyz=True):
+    """g: run_gpu() result, c: oracle.Cloud."""
+    assert g["key"].shape == c.key.shape, (g["key"].shape, c.key.shape)
+    assert np.array_equal(g["key"], c.key), "voxel key sets differ"
+    assert np.array_equal(g["tag"], c.tag), "winning (frame,pixel) tags differ"
+    assert np.array_equal(g["bgr"], c.bgr), "colours differ"
+    if exact_xyz:
+        # bit-exact, NaN-aware
+        assert np.array_equal(g["xyz"].view(np.uint64) == c.xyz.view(np.uint64),
+                              np.ones_like(c.xyz, dtype=bool)) or \
+            np.array_equal(np.nan_to_num(g["xyz"], nan=1.25e300), np.nan_to_num(c.xyz, nan=1.25e300)), \
+            "fused coordinates differ"
+    else:
+        np.testing.assert_allclose(g["xyz"], c.xyz, rtol=1e-5, atol=0, equal_nan=True)
+    assert np.array_equal(g["frame_before"], c.frame_before), "per-frame 'before' counts differ"
+    assert np.array_equal(g["frame_after"], c.frame_after), "per-frame 'after' counts differ"
+    st = g["stats"]
+    assert st["global_before"] == c.global_before
+    assert st["global_after"] == c.global_after
+    for k in ("n_px", "n_gather", "n_acc", "n_hit", "n_vox"):
+        assert st[k] == c.counters[k], (k, st[k], c.counters[k])
