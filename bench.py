@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- fused depth px/s of the MI355X dense-fusion path (BASELINE.json metric).
+
+One "step" = one full sfm_fusion_run over the workload: masks cleared, every keyframe fused in
+order, voxel first-wins filter, compacted cloud left in HBM.  Inputs are synthetic
+(sfm_amd/synth.py) and already resident in HBM when the timed region starts.
+
+N=1 workload = BASELINE.json configs[1]: 500 keyframes 640x480, TUM-like intrinsics, depth in
+millimetres, 1 cm voxels (voxel_size=10 raw units), T_dist=500 raw units, temporal
+neighbours +-4.  N>1: weak scaling -- every rank fuses its own 500-keyframe trajectory through
+the same room (one covisibility component per rank: components are the unit the
+visibility-mask chain allows to shard), then the per-rank voxel tables are
+exchanged by voxel-key hash partition (RCCL all-to-all) and min-reduced by their owners.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+WORKLOADS = {
+    # name: (keyframes per GPU, W, H, intrinsics, voxel_size, T_dist)
+    "c2_500kf_640x480_1cm": (500, 640, 480, (525.0, 525.0, 319.5, 239.5), 10.0, 500.0),
+    "c3_2000kf_1280x720_1cm": (2000, 1280, 720, (913.848, 913.602, 642.941, 371.196), 10.0, 500.0),
+    "c5_10000kf_640x480_5mm": (10000, 640, 480, (525.0, 525.0, 319.5, 239.5), 5.0, 500.0),
+    "tiny_24kf_160x120": (24, 160, 120, (131.25, 131.25, 79.75, 59.75), 10.0, 500.0),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def fuse_bytes(st):
+    """Algorithmic bytes of the per-keyframe kernels (SURVEY.md 8d terms that those kernels
+    move): depth u16 + mask u8 per pixel, 2 B per neighbour depth gather, 3 B colour and one
+    16-B slot read+write per accepted pixel, 1 B per mask store."""
+    return 3 * st["n_px"] + 2 * st["n_gather"] + 3 * st["n_acc"] + st["n_hit"] + 32 * st["n_acc"]
+
+
+def total_bytes(st):
+    return fuse_bytes(st) + 27 * st["n_vox"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2_500kf_640x480_1cm", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=0, help="override keyframes per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=48)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from sfm_amd import fusion, synth
+
+    n_kf, W, H, K, voxel, t_dist = WORKLOADS[args.workload]
+    if args.frames:
+        n_kf = args.frames
+    # every rank ray-casts its own trajectory (component id = rank) on its own GPU
+    seq = synth.make_sequence(n_kf, W, H, K=K, device=dev, seed=20240315 + rank,
+                              components=1, radius_m=0.8 * (1.0 + 0.07 * rank))
+    torch.cuda.synchronize()
+    params = fusion.default_params(voxel_size=voxel, T_dist=t_dist)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = fusion.FusionContext(params, local_rank, stream)
+    for i in range(n_kf):
+        ctx.add_keyframe_device(seq.depth[i].data_ptr(), seq.bgr[i].data_ptr(), W, H,
+                                seq.K[i], seq.T_wk[i], seq.T_kw[i])
+    for i in range(n_kf):
+        ctx.set_neighbors(i, seq.nbrs[i])
+
+    merger = None
+    if world > 1:
+        from sfm_amd import dist_fusion
+        merger = dist_fusion.VoxelExchange(ctx, rank, world, dev)
+
+    def step():
+        ctx.run()
+        if merger is not None:
+            merger.exchange_and_reduce()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    st = ctx.stats()
+    n_points = merger.n_points if merger is not None else st["n_vox"]
+    if world > 1:
+        t = torch.tensor([n_points], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        n_points = int(t.item())
+
+    # roofline of the dominant kernel (fuse_frame_kernel): one extra, untimed, run with
+    # per-dispatch start/stop events on the library's stream
+    ctx.set_profiling(True)
+    ctx.run()
+    pst = ctx.stats()
+    ctx.set_profiling(False)
+    launches = max(1, pst["fuse_kernel_launches"])
+    avg_launch_s = pst["fuse_kernel_sum_ms"] * 1e-3 / launches
+    bytes_per_launch = fuse_bytes(pst) / launches
+    achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload and not args.frames:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    px_total = n_kf * W * H * world
+    value = px_total * args.steps / dt
+    out = {
+        "metric": "fused depth px/sec (whole node)",
+        "value": value,
+        "unit": "px/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": args.workload, "keyframes_per_gpu": n_kf, "width": W, "height": H,
+                   "voxel_size_raw_units": voxel, "T_dist_raw_units": t_dist,
+                   "depth_unit": "mm", "neighbours": "temporal +-4",
+                   "sharding": "one covisibility component per GPU" if world > 1 else "single GPU"},
+        "points_per_s": n_points * args.steps / dt,
+        "output_points": n_points,
+        "device_ms_per_step_rank0": st["last_run_ms"],
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "fuse_frame_kernel",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "bytes_per_launch": bytes_per_launch,
+            "avg_launch_us": avg_launch_s * 1e6,
+            "launches_per_step": launches,
+            "whole_step_frac": total_bytes(st) / (st["last_run_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if st["last_run_ms"] > 0 else None,
+        },
+        "table": {"capacity": st["table_capacity"], "used": st["table_used"],
+                  "load_factor": st["table_used"] / max(1, st["table_capacity"]),
+                  "max_probe": st["max_probe"]},
+        "counters": {k: st[k] for k in ("n_px", "n_gather", "n_acc", "n_hit", "n_vox")},
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(seq, min(args.cpu_sample_frames, n_kf), W, H, voxel, t_dist)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(seq, n_sample, W, H, voxel, t_dist):
+    """Times the CPU oracle (a restatement of the reference, kind "port") on the first
+    n_sample keyframes of the same workload, on this box's host cores."""
+    from oracle import oracle
+    frames = seq.frame_dicts(0, n_sample)
+    p = oracle.default_params(voxel_size=voxel, T_dist=t_dist)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    c = oracle.fuse(frames, p, n_threads=threads)
+    t_mt = time.perf_counter() - t0
+    n1 = max(1, n_sample // 4)
+    t0 = time.perf_counter()
+    oracle.fuse(frames[:n1] if n1 == n_sample else seq.frame_dicts(0, n1), p, n_threads=1)
+    t_1 = time.perf_counter() - t0
+    return {
+        "value": n_sample * W * H / t_mt,
+        "unit": "px/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"first {n_sample} keyframes of the workload, pixel loop over {threads} host threads "
+                  f"(mirrors the reference's par_unseq loop); single-thread figure on the first {n1}",
+        "value_1core": n1 * W * H / t_1,
+        "seconds": t_mt + t_1,
+        "sample_points": int(c.key.shape[0]),
+        "note": "restatement without the reference's per-pixel shared_ptr/cv::Mat refcount traffic: "
+                "expected to be faster than the real reference binary",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,10 @@ typedef struct sfm_fusion_stats {
     uint64_t max_probe;     /* longest probe sequence seen by an insert */
     double last_run_ms;     /* device time of the last sfm_fusion_run (HIP events) */
     double frame_kernels_ms;/* device time between first and last per-frame kernel */
+    /* filled when sfm_fusion_set_profiling(ctx,1): per-dispatch start/stop timestamps of the
+     * per-keyframe kernel (same clock rocprofv3 --kernel-trace reads) */
+    uint64_t fuse_kernel_launches;
+    double fuse_kernel_sum_ms;
 } sfm_fusion_stats;
 
 void sfm_fusion_default_params(sfm_fusion_params *p);
@@ -121,6 +125,9 @@ int sfm_fusion_read_points(sfm_fusion_ctx *ctx, double *xyz, int32_t *bgr, uint6
                            uint64_t *tag);
 
 int sfm_fusion_get_stats(sfm_fusion_ctx *ctx, sfm_fusion_stats *out);
+/* Measurement aid (no reference counterpart): record start/stop events around every
+ * per-keyframe kernel dispatch of subsequent runs. */
+int sfm_fusion_set_profiling(sfm_fusion_ctx *ctx, int enable);
 /* per-frame "Points before/after voxel filter" (:118-120); arrays of n_frames. */
 int sfm_fusion_get_frame_counts(sfm_fusion_ctx *ctx, uint64_t *before, uint64_t *after);
 

@@ -3,6 +3,7 @@
 // computes needs a HIP device and fails with SFM_E_HIP otherwise.
 #include "../../include/sfm_fusion.h"
 #include "fusion_kernels.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -55,6 +56,8 @@ struct sfm_fusion_ctx {
     Counters *d_ctr = nullptr;
     Counters *h_ctr = nullptr;  // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool profile = false;               // per-launch start/stop events on the frame kernels
+    std::vector<hipEvent_t> kev;        // 2 per keyframe when profiling
 
     uint64_t total_px = 0;
     uint64_t n_out = 0;
@@ -209,6 +212,12 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t list_cap, uint32_t 
         HIP_TRY(c, hipMemsetAsync(c->d_fbefore.p, 0, n * sizeof(unsigned long long), s));
         HIP_TRY(c, hipMemsetAsync(c->d_fafter.p, 0, n * sizeof(unsigned long long), s));
     }
+    if (c->profile)
+        while (c->kev.size() < 2 * n) {
+            hipEvent_t e;
+            HIP_TRY(c, hipEventCreate(&e));
+            c->kev.push_back(e);
+        }
     FuseArgs a;
     a.table = c->d_table.p;
     a.mark = c->d_mark.p;
@@ -236,8 +245,13 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t list_cap, uint32_t 
         if (px == 0) continue;
         const uint32_t tiles = (uint32_t)((px + kTile - 1) / kTile);
         a.f = (uint32_t)i;
-        hipLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(kWave), 0, s,
-                           (const FrameDev *)c->d_frames.p, (const uint32_t *)c->d_nbr.p, a);
+        if (c->profile)
+            hipExtLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(kWave), 0, s, c->kev[2 * i],
+                                  c->kev[2 * i + 1], 0, (const FrameDev *)c->d_frames.p,
+                                  (const uint32_t *)c->d_nbr.p, a);
+        else
+            hipLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(kWave), 0, s,
+                               (const FrameDev *)c->d_frames.p, (const uint32_t *)c->d_nbr.p, a);
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
@@ -343,6 +357,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->kev) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -469,7 +484,24 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     st.last_run_ms = ms;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
     st.frame_kernels_ms = ms;
+    st.fuse_kernel_launches = 0;
+    st.fuse_kernel_sum_ms = 0;
+    if (c->profile) {
+        for (size_t i = 0; i < n; i++) {
+            if ((uint64_t)c->frames[i].W * c->frames[i].H == 0) continue;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[2 * i], c->kev[2 * i + 1]));
+            st.fuse_kernel_sum_ms += ms;
+            st.fuse_kernel_launches++;
+        }
+    }
     c->have_result = true;
+    return SFM_OK;
+}
+
+int sfm_fusion_set_profiling(sfm_fusion_ctx *c, int enable)
+{
+    if (!c) return SFM_E_INVALID;
+    c->profile = enable != 0;
     return SFM_OK;
 }
 

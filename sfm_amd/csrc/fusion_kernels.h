@@ -289,6 +289,7 @@ __device__ __forceinline__ void process_batch(const FrameDev *__restrict__ frame
         base = __shfl(base, __ffsll((long long)m) - 1);
         if (ok) {
             const unsigned long long idx = base + (unsigned)__popcll(m & lanemask_lt());
+#ifndef SFM_ABLATE_LIST
             if (idx < a.list_cap) {
                 a.list_key[idx] = key;
                 a.list_tag[idx] = tag;
@@ -299,6 +300,8 @@ __device__ __forceinline__ void process_batch(const FrameDev *__restrict__ frame
             } else {
                 atomicOr(&a.ctr->err, kErrListFull);
             }
+#endif
+#ifndef SFM_ABLATE_TABLE
             unsigned probes;
             const uint64_t h = table_insert(a, key, tag, probes);
             if (h == ~0ull) {
@@ -310,6 +313,7 @@ __device__ __forceinline__ void process_batch(const FrameDev *__restrict__ frame
                     if (atomicMax(&a.mark[h], a.f + 1u) < a.f + 1u) c_after++;
                 }
             }
+#endif
         }
     }
 }

@@ -34,6 +34,7 @@ EXPORTS = [
     "sfm_fusion_add_keyframe", "sfm_fusion_set_neighbors", "sfm_fusion_run",
     "sfm_fusion_num_points", "sfm_fusion_read_points", "sfm_fusion_get_stats",
     "sfm_fusion_get_frame_counts", "sfm_fusion_last_error", "sfm_fusion_version",
+    "sfm_fusion_set_profiling",
 ]
 
 
@@ -54,6 +55,7 @@ class FusionStats(C.Structure):
         ("n_hit", C.c_uint64), ("n_vox", C.c_uint64), ("table_capacity", C.c_uint64),
         ("table_used", C.c_uint64), ("max_probe", C.c_uint64),
         ("last_run_ms", C.c_double), ("frame_kernels_ms", C.c_double),
+        ("fuse_kernel_launches", C.c_uint64), ("fuse_kernel_sum_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -74,10 +76,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} is missing: run ./build.sh (hipcc --offload-arch=gfx950). "
+    path = os.environ.get("SFM_FUSION_LIB", LIB_PATH)  # A/B builds of the same HIP library
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run ./build.sh (hipcc --offload-arch=gfx950). "
                           "sfm_amd has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
     dp = C.POINTER(C.c_double)
     L.sfm_fusion_default_params.argtypes = [C.POINTER(FusionParams)]
@@ -92,6 +95,7 @@ def load_library():
     L.sfm_fusion_read_points.argtypes = [vp, vp, vp, vp, vp]
     L.sfm_fusion_get_stats.argtypes = [vp, C.POINTER(FusionStats)]
     L.sfm_fusion_get_frame_counts.argtypes = [vp, vp, vp]
+    L.sfm_fusion_set_profiling.argtypes = [vp, C.c_int]
     L.sfm_fusion_last_error.argtypes = [vp]
     L.sfm_fusion_last_error.restype = C.c_char_p
     L.sfm_fusion_version.restype = C.c_char_p
@@ -182,6 +186,9 @@ class FusionContext:
         nb = np.ascontiguousarray(nbrs, dtype=np.uint32)
         self._check(self._L.sfm_fusion_set_neighbors(
             self._h, int(idx), nb.ctypes.data_as(C.POINTER(C.c_uint32)), nb.size))
+
+    def set_profiling(self, enable: bool):
+        self._check(self._L.sfm_fusion_set_profiling(self._h, int(bool(enable))))
 
     def run(self):
         self._check(self._L.sfm_fusion_run(self._h))
