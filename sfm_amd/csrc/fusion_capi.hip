@@ -1,6 +1,13 @@
 // fusion_capi.hip -- host side of libsfm_fusion.so: the C ABI of include/sfm_fusion.h over
 // the gfx950 kernels in fusion_kernels.h.  No CPU fallback exists: every entry point that
 // computes needs a HIP device and fails with SFM_E_HIP otherwise.
+//
+// Stream plan of one run (DESIGN.md "Streams"):
+//   stream A (caller's or private): memsets, then fuse_frame_kernel per keyframe, strictly in
+//            order -- the visibility masks make this a chain.
+//   stream B (private): table_group_kernel per group of 32 keyframes, each waiting on the event
+//            of the group's last keyframe kernel; it overlaps the chain on stream A.
+//   stream A then waits for B, and finalize_kernel compacts the winners.
 #include "../../include/sfm_fusion.h"
 #include "fusion_kernels.h"
 #include <hip/hip_ext.h>
@@ -26,6 +33,7 @@ struct HostFrame {
     uint16_t *d_depth = nullptr;
     uint8_t *d_bgr = nullptr;
     std::vector<uint32_t> nbrs;  // raw Map::get_neighbors list
+    uint32_t n_filtered = 0;     // neighbours left after the :72-89 filter
 };
 
 template <typename T>
@@ -34,12 +42,19 @@ struct DevBuf {
     uint64_t n = 0;
 };
 
+struct HostCounters {  // pinned snapshot read back after the frame loop
+    Counters ctr;
+    alignas(64) unsigned long long cursor[kListShards * 8];
+    alignas(64) StatShard stat[kStatShards];
+};
+
 }  // namespace
 
 struct sfm_fusion_ctx {
     sfm_fusion_params prm;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // stream A
+    hipStream_t stream_b = nullptr;  // stream B (table kernels)
     bool own_stream = false;
     std::vector<HostFrame> frames;
     bool layout_dirty = true;
@@ -48,16 +63,20 @@ struct sfm_fusion_ctx {
     DevBuf<uint32_t> d_nbr;
     DevBuf<uint8_t> d_masks;
     DevBuf<Slot> d_table;
-    DevBuf<uint32_t> d_mark;
+    DevBuf<unsigned long long> d_mark;
     DevBuf<unsigned long long> d_list_key, d_list_tag, d_out_key, d_out_tag;
     DevBuf<double> d_list_xyz, d_out_xyz;
     DevBuf<uint32_t> d_list_bgr, d_out_bgr;
-    DevBuf<unsigned long long> d_fbefore, d_fafter;
-    Counters *d_ctr = nullptr;
-    Counters *h_ctr = nullptr;  // pinned
+    DevBuf<unsigned long long> d_fbefore, d_fafter, d_frame_end;
+    DevBuf<unsigned int> d_frame_done;
+    // one allocation: Counters | cursors | stat shards (zeroed by a single memset per run)
+    unsigned char *d_small = nullptr;
+    HostCounters *h_small = nullptr;  // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool profile = false;               // per-launch start/stop events on the frame kernels
-    std::vector<hipEvent_t> kev;        // 2 per keyframe when profiling
+    hipEvent_t ev_init = nullptr, ev_b_done = nullptr;
+    std::vector<hipEvent_t> gev;  // one per keyframe group
+    bool profile = false;         // per-launch start/stop events on the frame kernels
+    std::vector<hipEvent_t> kev;  // 2 per keyframe when profiling
 
     uint64_t total_px = 0;
     uint64_t n_out = 0;
@@ -68,6 +87,18 @@ struct sfm_fusion_ctx {
 };
 
 namespace {
+
+constexpr size_t kSmallBytes = sizeof(HostCounters);
+
+Counters *dev_ctr(sfm_fusion_ctx *c) { return reinterpret_cast<Counters *>(c->d_small); }
+unsigned long long *dev_cursor(sfm_fusion_ctx *c)
+{
+    return reinterpret_cast<unsigned long long *>(c->d_small + offsetof(HostCounters, cursor));
+}
+StatShard *dev_stat(sfm_fusion_ctx *c)
+{
+    return reinterpret_cast<StatShard *>(c->d_small + offsetof(HostCounters, stat));
+}
 
 int fail(sfm_fusion_ctx *c, int code, const std::string &msg)
 {
@@ -157,7 +188,7 @@ int build_layout(sfm_fusion_ctx *c)
     std::vector<FrameDev> fd(n);
     std::vector<uint32_t> nbr;
     for (size_t i = 0; i < n; i++) {
-        const HostFrame &f = c->frames[i];
+        HostFrame &f = c->frames[i];
         FrameDev &d = fd[i];
         std::memcpy(d.K, f.K, sizeof d.K);
         rows3(f.Twk, d.Twk);
@@ -171,6 +202,7 @@ int build_layout(sfm_fusion_ctx *c)
         for (uint32_t j : f.nbrs)
             if (neighbor_kept(c->prm, f, c->frames[j])) nbr.push_back(j);
         d.nbr_count = (uint32_t)nbr.size() - d.nbr_begin;
+        f.n_filtered = d.nbr_count;
         d.order = (uint32_t)i;
         d.pad = 0;
         if (d.nbr_count > SFM_MAX_NEIGHBORS)
@@ -183,6 +215,8 @@ int build_layout(sfm_fusion_ctx *c)
     if ((rc = ensure(c, c->d_nbr, nbr.size()))) return rc;
     if ((rc = ensure(c, c->d_fbefore, n))) return rc;
     if ((rc = ensure(c, c->d_fafter, n))) return rc;
+    if ((rc = ensure(c, c->d_frame_end, n * kListShards))) return rc;
+    if ((rc = ensure(c, c->d_frame_done, n))) return rc;
     if (n) HIP_TRY(c, hipMemcpy(c->d_frames.p, fd.data(), n * sizeof(FrameDev), hipMemcpyHostToDevice));
     if (!nbr.empty())
         HIP_TRY(c, hipMemcpy(c->d_nbr.p, nbr.data(), nbr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -190,9 +224,11 @@ int build_layout(sfm_fusion_ctx *c)
     return SFM_OK;
 }
 
-int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t list_cap, uint32_t *err_bits)
+// One attempt with fixed capacities.  table_cap is a power of two.
+int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t *err_bits)
 {
     const size_t n = c->frames.size();
+    const uint64_t list_cap = shard_cap * kListShards;
     int rc;
     if ((rc = ensure(c, c->d_table, table_cap))) return rc;
     if ((rc = ensure(c, c->d_mark, table_cap))) return rc;
@@ -200,17 +236,11 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t list_cap, uint32_t 
     if ((rc = ensure(c, c->d_list_tag, list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_xyz, 3 * list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_bgr, list_cap))) return rc;
-    table_cap = pow2_at_least(table_cap);
-    // a previous run may have left bigger buffers; use exactly table_cap slots (power of 2)
-    hipStream_t s = c->stream;
-    HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    if (c->d_masks.n) HIP_TRY(c, hipMemsetAsync(c->d_masks.p, 0, c->d_masks.n, s));  // :40-45
-    HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0xFF, table_cap * sizeof(Slot), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_mark.p, 0, table_cap * sizeof(uint32_t), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), s));
-    if (n) {
-        HIP_TRY(c, hipMemsetAsync(c->d_fbefore.p, 0, n * sizeof(unsigned long long), s));
-        HIP_TRY(c, hipMemsetAsync(c->d_fafter.p, 0, n * sizeof(unsigned long long), s));
+    const size_t n_groups = (n + kGroup - 1) / kGroup;
+    while (c->gev.size() < n_groups) {
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->gev.push_back(e);
     }
     if (c->profile)
         while (c->kev.size() < 2 * n) {
@@ -218,18 +248,34 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t list_cap, uint32_t 
             HIP_TRY(c, hipEventCreate(&e));
             c->kev.push_back(e);
         }
+    hipStream_t sa = c->stream, sb = c->stream_b;
+    HIP_TRY(c, hipEventRecord(c->ev[0], sa));
+    if (c->d_masks.n) HIP_TRY(c, hipMemsetAsync(c->d_masks.p, 0, c->d_masks.n, sa));  // :40-45
+    HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0xFF, table_cap * sizeof(Slot), sa));
+    HIP_TRY(c, hipMemsetAsync(c->d_mark.p, 0, table_cap * sizeof(unsigned long long), sa));
+    HIP_TRY(c, hipMemsetAsync(c->d_small, 0, kSmallBytes, sa));
+    if (n) {
+        HIP_TRY(c, hipMemsetAsync(c->d_fbefore.p, 0, n * sizeof(unsigned long long), sa));
+        HIP_TRY(c, hipMemsetAsync(c->d_fafter.p, 0, n * sizeof(unsigned long long), sa));
+        HIP_TRY(c, hipMemsetAsync(c->d_frame_done.p, 0, n * sizeof(unsigned int), sa));
+        HIP_TRY(c, hipMemsetAsync(c->d_frame_end.p, 0, n * kListShards * sizeof(unsigned long long), sa));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_init, sa));
+    HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_init, 0));
+
+    ListDev list;
+    list.key = c->d_list_key.p;
+    list.tag = c->d_list_tag.p;
+    list.xyz = c->d_list_xyz.p;
+    list.bgr = c->d_list_bgr.p;
+    list.shard_cap = shard_cap;
+    list.cursor = dev_cursor(c);
+    list.frame_end = c->d_frame_end.p;
+
     FuseArgs a;
-    a.table = c->d_table.p;
-    a.mark = c->d_mark.p;
-    a.table_mask = table_cap - 1;
-    a.list_key = c->d_list_key.p;
-    a.list_tag = c->d_list_tag.p;
-    a.list_xyz = c->d_list_xyz.p;
-    a.list_bgr = c->d_list_bgr.p;
-    a.list_cap = list_cap;
-    a.ctr = c->d_ctr;
-    a.frame_before = c->d_fbefore.p;
-    a.frame_after = c->d_fafter.p;
+    a.list = list;
+    a.frame_done = c->d_frame_done.p;
+    a.stat = dev_stat(c);
     a.P.base_line = c->prm.base_line;
     a.P.T_cov = c->prm.T_cov;
     a.P.voxel_size = c->prm.voxel_size;
@@ -239,27 +285,58 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t list_cap, uint32_t 
     a.P.S2 = c->prm.S[2];
     a.P.depth_div = c->prm.depth_div;
     a.P.close_frac = c->prm.close_frac;
-    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+
+    TableArgs t;
+    t.table = c->d_table.p;
+    t.mark = c->d_mark.p;
+    t.table_mask = table_cap - 1;
+    t.list = list;
+    t.ctr = dev_ctr(c);
+    t.frame_before = c->d_fbefore.p;
+    t.frame_after = c->d_fafter.p;
+
+    HIP_TRY(c, hipEventRecord(c->ev[1], sa));
     for (size_t i = 0; i < n; i++) {  // :48-52, strictly in order
-        const uint64_t px = (uint64_t)c->frames[i].W * c->frames[i].H;
-        if (px == 0) continue;
-        const uint32_t tiles = (uint32_t)((px + kTile - 1) / kTile);
+        const HostFrame &f = c->frames[i];
+        const uint64_t px = (uint64_t)f.W * f.H;
+        // a keyframe without pixels still runs one (empty) workgroup so that its list
+        // boundary frame_end[] is published
+        const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, (px + kTile - 1) / kTile);
+        const uint32_t nw = std::min<uint32_t>(std::max<uint32_t>(f.n_filtered, 1), kMaxWaves);
+        const size_t lds = fuse_lds_bytes(f.n_filtered);
         a.f = (uint32_t)i;
         if (c->profile)
-            hipExtLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(kWave), 0, s, c->kev[2 * i],
+            hipExtLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(nw * kWave), lds, sa, c->kev[2 * i],
                                   c->kev[2 * i + 1], 0, (const FrameDev *)c->d_frames.p,
                                   (const uint32_t *)c->d_nbr.p, a);
         else
-            hipLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(kWave), 0, s,
+            hipLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(nw * kWave), lds, sa,
                                (const FrameDev *)c->d_frames.p, (const uint32_t *)c->d_nbr.p, a);
+        if (i % kGroup == kGroup - 1 || i + 1 == n) {
+            const size_t g = i / kGroup;
+            HIP_TRY(c, hipEventRecord(c->gev[g], sa));
+            HIP_TRY(c, hipStreamWaitEvent(sb, c->gev[g], 0));
+            t.f0 = (uint32_t)(g * kGroup);
+            t.f1 = (uint32_t)(i + 1);
+            t.group = (uint32_t)g;
+            hipLaunchKernelGGL(table_group_kernel, dim3(64, kListShards), dim3(256), 0, sb, t);
+        }
     }
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev[2], s));
-    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    *err_bits = c->h_ctr->err;
-    if (*err_bits) return SFM_OK;  // caller decides: grow and retry, or report
-    const uint64_t n_list = c->h_ctr->list_count;
+    HIP_TRY(c, hipEventRecord(c->ev[2], sa));
+    HIP_TRY(c, hipEventRecord(c->ev_b_done, sb));
+    HIP_TRY(c, hipStreamWaitEvent(sa, c->ev_b_done, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_small, c->d_small, kSmallBytes, hipMemcpyDeviceToHost, sa));
+    HIP_TRY(c, hipStreamSynchronize(sa));
+    uint32_t err = c->h_small->ctr.err;
+    for (int s = 0; s < kStatShards; s++) err |= c->h_small->stat[s].err;
+    uint64_t n_list = 0;
+    for (int s = 0; s < kListShards; s++) {
+        if (c->h_small->cursor[s * 8] > shard_cap) err |= kErrListFull;
+        n_list += std::min<uint64_t>(c->h_small->cursor[s * 8], shard_cap);
+    }
+    *err_bits = err;
+    if (err) return SFM_OK;  // caller decides: grow and retry, or report
     if ((rc = ensure(c, c->d_out_key, n_list))) return rc;
     if ((rc = ensure(c, c->d_out_tag, n_list))) return rc;
     if ((rc = ensure(c, c->d_out_xyz, 3 * n_list))) return rc;
@@ -268,23 +345,20 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t list_cap, uint32_t 
         FinalizeArgs fa;
         fa.table = c->d_table.p;
         fa.table_mask = table_cap - 1;
-        fa.list_key = c->d_list_key.p;
-        fa.list_tag = c->d_list_tag.p;
-        fa.list_xyz = c->d_list_xyz.p;
-        fa.list_bgr = c->d_list_bgr.p;
-        fa.n_list = n_list;
-        fa.ctr = c->d_ctr;
+        fa.list = list;
+        fa.ctr = dev_ctr(c);
         fa.out_xyz = c->d_out_xyz.p;
         fa.out_bgr = c->d_out_bgr.p;
         fa.out_key = c->d_out_key.p;
         fa.out_tag = c->d_out_tag.p;
-        const uint64_t blocks = std::min<uint64_t>((n_list + 255) / 256, 2048);
-        hipLaunchKernelGGL(finalize_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, fa);
+        const uint64_t per_shard = (n_list / kListShards + 255) / 256 + 1;
+        const uint32_t bx = (uint32_t)std::min<uint64_t>(per_shard, 256);
+        hipLaunchKernelGGL(finalize_kernel, dim3(bx, kListShards), dim3(256), 0, sa, fa);
         HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipEventRecord(c->ev[3], s));
-    HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipEventRecord(c->ev[3], sa));
+    HIP_TRY(c, hipMemcpyAsync(c->h_small, c->d_small, kSmallBytes, hipMemcpyDeviceToHost, sa));
+    HIP_TRY(c, hipStreamSynchronize(sa));
     return SFM_OK;
 }
 
@@ -329,9 +403,12 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
         ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
         c->own_stream = ok;
     }
-    ok = ok && hipMalloc(&c->d_ctr, sizeof(Counters)) == hipSuccess;
-    ok = ok && hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc(&c->d_small, kSmallBytes) == hipSuccess;
+    ok = ok && hipHostMalloc(&c->h_small, kSmallBytes, hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_b_done, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         sfm_fusion_destroy(c);
         return SFM_E_HIP;
@@ -345,6 +422,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
     for (auto &f : c->frames) {
         if (f.d_depth) (void)hipFree(f.d_depth);
         if (f.d_bgr) (void)hipFree(f.d_bgr);
@@ -352,12 +430,17 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     release(c->d_frames); release(c->d_nbr); release(c->d_masks); release(c->d_table);
     release(c->d_mark); release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
-    release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter);
-    if (c->d_ctr) (void)hipFree(c->d_ctr);
-    if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_frame_end);
+    release(c->d_frame_done);
+    if (c->d_small) (void)hipFree(c->d_small);
+    if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    if (c->ev_init) (void)hipEventDestroy(c->ev_init);
+    if (c->ev_b_done) (void)hipEventDestroy(c->ev_b_done);
+    for (auto &e : c->gev) (void)hipEventDestroy(e);
     for (auto &e : c->kev) (void)hipEventDestroy(e);
+    if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -371,7 +454,7 @@ int sfm_fusion_add_keyframe(sfm_fusion_ctx *c, uint32_t order_idx, int32_t W, in
     if (order_idx != c->frames.size())
         return fail(c, SFM_E_INVALID, "keyframes must be added in order 0,1,2,...");
     if (W < 0 || H < 0 || !K || !T_wk || !T_kw) return fail(c, SFM_E_INVALID, "bad keyframe argument");
-    if ((uint64_t)W * (uint64_t)H > 0xFFFFFFFFull) return fail(c, SFM_E_INVALID, "image too large");
+    if ((uint64_t)W * (uint64_t)H > 0xFFFFFF00ull) return fail(c, SFM_E_INVALID, "image too large");
     const uint64_t px = (uint64_t)W * H;
     if (px && (!depth || !bgr)) return fail(c, SFM_E_INVALID, "null image pointer");
     if (px && (depth_stride < 2ull * W || bgr_stride < 3ull * W))
@@ -432,45 +515,53 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     if (c->layout_dirty && (rc = build_layout(c))) return rc;
     c->have_result = false;
     const bool fixed_tab = c->prm.table_capacity != 0, fixed_list = c->prm.max_points != 0;
-    uint64_t list_cap = fixed_list ? c->prm.max_points
-                                   : std::max<uint64_t>(c->d_list_key.n, std::max<uint64_t>(c->total_px / 4, 1 << 16));
+    // Sizes: explicit, else what the previous run ended with, else a first guess that the
+    // retry loop below doubles until the run fits.
+    uint64_t shard_cap = fixed_list ? (c->prm.max_points + kListShards - 1) / kListShards
+                                    : std::max<uint64_t>(c->d_list_key.n / kListShards,
+                                                         std::max<uint64_t>(c->total_px / 4, 1 << 16) / kListShards);
     uint64_t table_cap = fixed_tab ? pow2_at_least(c->prm.table_capacity)
-                                   : std::max<uint64_t>(pow2_at_least(c->d_table.n ? c->d_table.n : 0),
-                                                        pow2_at_least(std::max<uint64_t>(c->total_px / 2, 1 << 16)));
+                                   : pow2_at_least(std::max<uint64_t>(c->d_table.n,
+                                                                      std::max<uint64_t>(c->total_px / 8, 1 << 16)));
+    const uint64_t shard_max = c->total_px + kTile;  // every pixel live, all tiles in one shard
     for (int attempt = 0;; attempt++) {
         uint32_t err = 0;
-        if ((rc = run_once(c, table_cap, list_cap, &err))) return rc;
-        if (!err) break;
+        if ((rc = run_once(c, table_cap, shard_cap, &err))) return rc;
+        const bool crowded = !err && !fixed_tab && c->h_small->ctr.table_used * 2 > table_cap;
+        if (!err && !crowded) break;
         if (err & kErrKeyRange)
             return fail(c, SFM_E_KEY_RANGE,
                         "a fused point's voxel index is outside the packed key range of +-(2^20-1) per axis");
         bool grown = false;
-        if ((err & kErrListFull) && !fixed_list && list_cap < c->total_px) {
-            list_cap = std::min<uint64_t>(c->total_px, std::max<uint64_t>(list_cap * 2, c->h_ctr->list_count));
+        if ((err & kErrListFull) && !fixed_list && shard_cap < shard_max) {
+            uint64_t need = 0;
+            for (int s = 0; s < kListShards; s++) need = std::max<uint64_t>(need, c->h_small->cursor[s * 8]);
+            shard_cap = std::min<uint64_t>(shard_max, std::max<uint64_t>(shard_cap * 2, need + need / 8));
             grown = true;
         }
-        if ((err & kErrTableFull) && !fixed_tab && attempt < 8) {
-            table_cap *= 2;
+        if (((err & kErrTableFull) || crowded) && !fixed_tab && attempt < 16) {
+            table_cap *= 2;  // keeps the load factor under 1/2
             grown = true;
         }
         if (!grown) {
-            if (err & kErrListFull) return fail(c, SFM_E_CAPACITY, "accepted-point list capacity (max_points) exhausted");
+            if (err & kErrListFull) return fail(c, SFM_E_CAPACITY, "candidate list capacity (max_points) exhausted");
             return fail(c, SFM_E_TABLE_FULL, "voxel table capacity exhausted");
         }
     }
-    // keep the table under half full so probe sequences stay short on the next run
-    c->n_out = c->h_ctr->out_count;
+    c->n_out = c->h_small->ctr.out_count;
     sfm_fusion_stats &st = c->stats;
     std::memset(&st, 0, sizeof st);
     st.n_frames = n;
     st.n_px = c->total_px;
-    st.n_gather = c->h_ctr->n_gather;
-    st.n_hit = c->h_ctr->n_hit;
+    for (int s = 0; s < kStatShards; s++) {
+        st.n_gather += c->h_small->stat[s].n_gather;
+        st.n_hit += c->h_small->stat[s].n_hit;
+    }
     st.n_vox = c->n_out;
     st.global_after = c->n_out;
-    st.table_capacity = pow2_at_least(table_cap);
-    st.table_used = c->h_ctr->table_used;
-    st.max_probe = c->h_ctr->max_probe;
+    st.table_capacity = table_cap;
+    st.table_used = c->h_small->ctr.table_used;
+    st.max_probe = c->h_small->ctr.max_probe;
     c->fbefore.assign(n, 0);
     c->fafter.assign(n, 0);
     if (n) {
@@ -488,7 +579,6 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     st.fuse_kernel_sum_ms = 0;
     if (c->profile) {
         for (size_t i = 0; i < n; i++) {
-            if ((uint64_t)c->frames[i].W * c->frames[i].H == 0) continue;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[2 * i], c->kev[2 * i + 1]));
             st.fuse_kernel_sum_ms += ms;
             st.fuse_kernel_launches++;
@@ -569,15 +659,13 @@ int sfm_fusion_get_frame_counts(sfm_fusion_ctx *c, uint64_t *before, uint64_t *a
 {
     if (!c) return SFM_E_INVALID;
     if (!c->have_result) return fail(c, SFM_E_INVALID, "no result: call sfm_fusion_run first");
-    const size_t n = c->frames.size();
     if (before) std::copy(c->fbefore.begin(), c->fbefore.end(), before);
     if (after) std::copy(c->fafter.begin(), c->fafter.end(), after);
-    (void)n;
     return SFM_OK;
 }
 
 const char *sfm_fusion_last_error(sfm_fusion_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
 
-const char *sfm_fusion_version(void) { return "sfm_fusion 0.1 (gfx950)"; }
+const char *sfm_fusion_version(void) { return "sfm_fusion 0.2 (gfx950)"; }
 
 }  // extern "C"

@@ -5,13 +5,14 @@
 // clang -O3, no -march => SSE2, no FMA; reconstruction/CMakeLists.txt:3-5).  The Eigen
 // evaluation orders that matter are spelled out next to each function.
 //
-// Execution model: one workgroup = ONE wave64.  A wave streams 256-pixel tiles of the
-// current keyframe (coalesced ushort4 depth + uchar4 mask loads), ballot/popcount-compacts
-// the live pixels (mask==0 && depth>0) into a wave-private LDS queue, and runs the
-// expensive per-pixel work only on dense batches of 64 queued pixels, so every lane of a
-// batch is busy.  Keyframe/neighbour intrinsics and poses are wave-uniform: they are read
-// through the scalar cache into SGPRs (the CDNA form of "stage the pose once per tile"),
-// which keeps ~70 VGPRs per neighbour free compared with an LDS/VGPR copy.
+// Three kernels:
+//   fuse_frame_kernel   one launch per keyframe, in order (the visibility masks chain the
+//                       keyframes).  Workgroup = one 256-pixel tile, one wave
+//                       per (group of) neighbour keyframe(s).
+//   table_group_kernel  first-wins voxel filter for a group of <= 32 keyframes: open-addressing
+//                       hash in HBM, atomicCAS key claim + atomicMin order tag.  Runs on a
+//                       second stream, off the keyframe chain.
+//   finalize_kernel     gathers the winners into the output cloud.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,12 +21,16 @@ namespace sfm {
 
 constexpr int kWave = 64;
 constexpr int kPxPerLane = 4;
-constexpr int kTile = kWave * kPxPerLane;  // 256 pixels per wave-tile
+constexpr int kTile = kWave * kPxPerLane;  // 256 pixels per workgroup tile
 constexpr int kMaxK = 32;                  // SFM_MAX_NEIGHBORS
+constexpr int kMaxWaves = 8;               // waves per workgroup of fuse_frame_kernel
+constexpr int kListShards = 16;            // append cursors (one 64-B line each)
+constexpr int kStatShards = 64;
+constexpr int kGroup = 32;                 // keyframes per table_group_kernel launch
 constexpr uint64_t kEmpty = ~0ull;
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 
-// error bits in Counters::err
+// error bits
 constexpr uint32_t kErrTableFull = 1u;
 constexpr uint32_t kErrKeyRange = 2u;
 constexpr uint32_t kErrListFull = 4u;
@@ -53,29 +58,37 @@ struct Slot {
     unsigned long long tag;  // min over inserted (order<<32 | pixel); kEmpty when free
 };
 
-struct Counters {
-    unsigned long long list_count;
-    unsigned long long out_count;
-    unsigned long long table_used;
+struct StatShard {  // one 64-byte line per shard
     unsigned long long n_gather;
     unsigned long long n_hit;
+    unsigned int err;
+    unsigned int pad[11];
+};
+
+struct Counters {
+    unsigned long long out_count;
+    unsigned long long table_used;
     unsigned int err;
     unsigned int max_probe;
 };
 
+// Candidate-record list: kListShards independent append regions.  Shard s owns entries
+// [s*shard_cap, (s+1)*shard_cap).  Every live pixel reserves one entry; rejected pixels
+// leave tag == kEmpty.
+struct ListDev {
+    unsigned long long *key;
+    unsigned long long *tag;
+    double *xyz;             // 3 per entry
+    uint32_t *bgr;           // b | g<<8 | r<<16
+    uint64_t shard_cap;
+    unsigned long long *cursor;     // [kListShards * 8]  (stride 8 => one line per cursor)
+    unsigned long long *frame_end;  // [n_frames * kListShards] cursor values after each keyframe
+};
+
 struct FuseArgs {
-    Slot *table;
-    uint32_t *mark;          // per slot: 1 + last frame order that touched it
-    uint64_t table_mask;     // capacity-1
-    // accepted-point list (SoA)
-    unsigned long long *list_key;
-    unsigned long long *list_tag;
-    double *list_xyz;        // 3 per point
-    uint32_t *list_bgr;      // b | g<<8 | r<<16
-    uint64_t list_cap;
-    Counters *ctr;
-    unsigned long long *frame_before;
-    unsigned long long *frame_after;
+    ListDev list;
+    unsigned int *frame_done;  // [n_frames] finished workgroups
+    StatShard *stat;           // [kStatShards]
     DevParams P;
     uint32_t f;
 };
@@ -145,251 +158,318 @@ __device__ __forceinline__ unsigned long long lanemask_lt()
     return (1ull << lane_id()) - 1ull;
 }
 
-// Claims/finds the slot of `key` and lowers its tag to `tag` (first-wins == min tag,
-// dense_reconstruction.cpp:283-287 composed per frame and globally).  Returns the slot or
-// ~0 on a full table.  Stale plain reads are safe: keys never change once set, tags only
-// decrease.
-__device__ __forceinline__ uint64_t table_insert(const FuseArgs &a, unsigned long long key,
-                                                 unsigned long long tag, unsigned &probes)
-{
-    uint64_t h = mix64(key) & a.table_mask;
-    probes = 0;
-    for (;;) {
-        unsigned long long cur = a.table[h].key;
-        if (cur == kEmpty) {
-            cur = atomicCAS(&a.table[h].key, kEmpty, key);
-            if (cur == kEmpty) {
-                atomicAdd(&a.ctr->table_used, 1ull);
-                cur = key;
-            }
-        }
-        if (cur == key) {
-            if (a.table[h].tag > tag) atomicMin(&a.table[h].tag, tag);
-            return h;
-        }
-        h = (h + 1) & a.table_mask;
-        if (++probes > a.table_mask) return ~0ull;
-    }
-}
-
-// ---- the per-keyframe kernel ------------------------------------------------------------
-
-// process_pixel + geometric_check (dense_reconstruction.cpp:126-234) for one queued pixel
-// per lane.  `act` = this lane holds a real pixel.
-__device__ __forceinline__ void process_batch(const FrameDev *__restrict__ frames,
-                                              const uint32_t *__restrict__ nbr_idx,
-                                              const FuseArgs &a, const FrameDev &F, uint32_t pix,
-                                              bool act, uint32_t *s_hits,
-                                              unsigned &c_gather, unsigned &c_hit,
-                                              unsigned &c_acc, unsigned &c_after)
-{
-    const DevParams &P = a.P;
-    const unsigned lane = lane_id();
-    const int W = F.W;
-    const int u = (int)(pix % (uint32_t)W);
-    const int v = (int)(pix / (uint32_t)W);
-    bool ok = act;
-    double pwx = 0, pwy = 0, pwz = 0;
-    if (ok) {
-        const double d = (double)F.depth[pix];
-        const double tr = cov_trace(P, u, v, d, F.K[0]);             // :136
-        if (tr > P.T_cov) ok = false;                                // :138
-        const double x = ((double)u - F.K[2]) / F.K[0];              // pinhole.cpp:12
-        const double y = ((double)v - F.K[3]) / F.K[1];
-        const double pcx = x * d, pcy = y * d, pcz = d;              // :15-19
-        pwx = row_apply(F.Twk, 0, pcx, pcy, pcz);                    // :144
-        pwy = row_apply(F.Twk, 1, pcx, pcy, pcz);
-        pwz = row_apply(F.Twk, 2, pcx, pcy, pcz);
-    }
-    const uint32_t nK = F.nbr_count;
-    if (nK == 0) ok = false;                                         // :180
-    double wx = 0, wy = 0, wz = 0, total = 0;
-    unsigned n_obs = 0, n_close = 0;
-    for (uint32_t k = 0; k < nK; k++) {                              // :187
-        const uint32_t nb = nbr_idx[F.nbr_begin + k];
-        const FrameDev &L = frames[nb];
-        uint32_t hit = kNoHit;
-        if (ok) {
-            // KeyFrame::point_in_frame, keyframe.cpp:275-294 / pinhole.cpp:32-45
-            const double cx_ = row_apply(L.Tkw, 0, pwx, pwy, pwz);
-            const double cy_ = row_apply(L.Tkw, 1, pwx, pwy, pwz);
-            const double cz_ = row_apply(L.Tkw, 2, pwx, pwy, pwz);
-            const double px = (cx_ / cz_) * L.K[0] + L.K[2];
-            const double py = (cy_ / cz_) * L.K[1] + L.K[3];
-            // NaN projections are "not visible" (UB in the reference), hence the >= 0 form
-            const bool vis = (px >= 0) && (px < (double)L.W) && (py >= 0) && (py < (double)L.H) &&
-                             !(cz_ < 0);
-            if (vis) {
-                const int ix = (int)floor(px);
-                const int iy = (int)floor(py);
-                const uint32_t npix = (uint32_t)iy * (uint32_t)L.W + (uint32_t)ix;
-                const double d = (double)L.depth[npix];              // :193 (no d>0 test)
-                c_gather++;
-                const double x = ((double)ix - L.K[2]) / L.K[0];
-                const double y = ((double)iy - L.K[3]) / L.K[1];
-                const double qcx = x * d, qcy = y * d, qcz = d;
-                const double qx = row_apply(L.Twk, 0, qcx, qcy, qcz);
-                const double qy = row_apply(L.Twk, 1, qcx, qcy, qcz);
-                const double qz = row_apply(L.Twk, 2, qcx, qcy, qcz);
-                const double w = cov_trace(P, ix, iy, d, L.K[0]);    // :202
-                if (w < P.T_cov) {                                   // :204
-                    n_obs++;
-                    const double dx = qx - pwx, dy = qy - pwy, dz = qz - pwz;
-                    const double s = (dx * dx + dy * dy) + dz * dz;  // norm(): (e0+e1)+e2
-                    if (s < P.tau_dist2) n_close++;                  // :224
-                    const double inv = 1.0 / w;                      // :161-162
-                    wx = wx + qx * inv;
-                    wy = wy + qy * inv;
-                    wz = wz + qz * inv;
-                    total = total + inv;
-                    hit = npix;
-                }
-            }
-        }
-        s_hits[k * kWave + lane] = hit;
-    }
-    if (n_obs < 1) ok = false;                                       // :218
-    if ((double)n_close < (double)n_obs * P.close_frac) ok = false;  // :229
-
-    unsigned long long key = 0, tag = 0;
-    double fx = 0, fy = 0, fz = 0;
-    uint32_t col = 0;
-    if (ok) {
-        for (uint32_t k = 0; k < nK; k++) {                          // :152-154
-            const uint32_t hit = s_hits[k * kWave + lane];
-            if (hit != kNoHit) {
-                c_hit++;
-                const uint32_t nb = nbr_idx[F.nbr_begin + k];
-                // masks of already-processed keyframes are never read again
-                if (nb > a.f) frames[nb].mask[hit] = 255;
-            }
-        }
-        fx = wx / total; fy = wy / total; fz = wz / total;           // :164
-        const uint8_t *c = F.bgr + 3ull * pix;                       // :170, features.cpp:76-80
-        col = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
-        tag = ((unsigned long long)F.order << 32) | pix;
-        unsigned long long c0, c1, c2;
-        const int fits = (int)axis_code(voxel_index(fx, P.voxel_size), c0) &
-                         (int)axis_code(voxel_index(fy, P.voxel_size), c1) &
-                         (int)axis_code(voxel_index(fz, P.voxel_size), c2);
-        if (!fits) {
-            atomicOr(&a.ctr->err, kErrKeyRange);
-            ok = false;
-        } else {
-            key = (c0 << 42) | (c1 << 21) | c2;
-        }
-        c_acc++;
-    }
-    // wave-aggregated append to the accepted-point list
-    const unsigned long long m = __ballot(ok);
-    if (m != 0) {
-        unsigned long long base = 0;
-        const unsigned cnt = (unsigned)__popcll(m);
-        if (lane == (unsigned)__ffsll((long long)m) - 1u) base = atomicAdd(&a.ctr->list_count, (unsigned long long)cnt);
-        base = __shfl(base, __ffsll((long long)m) - 1);
-        if (ok) {
-            const unsigned long long idx = base + (unsigned)__popcll(m & lanemask_lt());
-#ifndef SFM_ABLATE_LIST
-            if (idx < a.list_cap) {
-                a.list_key[idx] = key;
-                a.list_tag[idx] = tag;
-                a.list_xyz[3 * idx + 0] = fx;
-                a.list_xyz[3 * idx + 1] = fy;
-                a.list_xyz[3 * idx + 2] = fz;
-                a.list_bgr[idx] = col;
-            } else {
-                atomicOr(&a.ctr->err, kErrListFull);
-            }
-#endif
-#ifndef SFM_ABLATE_TABLE
-            unsigned probes;
-            const uint64_t h = table_insert(a, key, tag, probes);
-            if (h == ~0ull) {
-                atomicOr(&a.ctr->err, kErrTableFull);
-            } else {
-                if (probes > a.ctr->max_probe) atomicMax(&a.ctr->max_probe, probes);
-                // per-frame voxel filter count (:119-120): first touch of this slot by frame f
-                if (a.mark[h] < a.f + 1u) {
-                    if (atomicMax(&a.mark[h], a.f + 1u) < a.f + 1u) c_after++;
-                }
-            }
-#endif
-        }
-    }
-}
-
 __device__ __forceinline__ unsigned wave_sum(unsigned v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
-// One launch per keyframe, in processing order (the visibility masks make keyframe k
-// depend on every earlier covisible keyframe).  frames/nbr_idx are never
-// written by any kernel: __restrict__ lets the compiler keep them on the scalar path.
-__global__ __launch_bounds__(64) void fuse_frame_kernel(const FrameDev *__restrict__ frames,
-                                                        const uint32_t *__restrict__ nbr_idx,
-                                                        FuseArgs a)
+// ---- the per-keyframe kernel ------------------------------------------------------------
+//
+// LDS per workgroup (dynamic, K = filtered neighbours of this keyframe):
+//   s_obs  [K][4][64] double   per neighbour, per lane: q*(1/w) (x,y,z) and 1/w
+//   s_hit  [K][64]    u32      re-observed pixel in the neighbour
+//   s_kept [K], s_close[K] u64 ballots: observation kept (:204) / within T_dist (:224)
+//   s_base u64, s_cnt[2] u32, s_qpix[256] u32, s_qd[256] u16   tile queue
+__host__ __device__ inline size_t fuse_lds_bytes(uint32_t K)
 {
-    __shared__ uint32_t s_queue[kWave + kTile];
-    __shared__ uint32_t s_hits[kMaxK * kWave];
+    return (size_t)K * (4 * 64 * 8 + 64 * 4 + 16) + 8 + 8 + kTile * 4 + kTile * 2;
+}
+
+// process_pixel + geometric_check (dense_reconstruction.cpp:126-234).
+__global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
+    const FrameDev *__restrict__ frames, const uint32_t *__restrict__ nbr_idx, FuseArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
     const unsigned lane = lane_id();
+    const unsigned w = threadIdx.x >> 6;
+    const unsigned NW = blockDim.x >> 6;
     const FrameDev &F = frames[a.f];
+    const DevParams &P = a.P;
+    const uint32_t K = F.nbr_count;
+    double *s_obs = reinterpret_cast<double *>(smem);
+    uint32_t *s_hit = reinterpret_cast<uint32_t *>(s_obs + (size_t)K * 256);
+    unsigned long long *s_kept = reinterpret_cast<unsigned long long *>(s_hit + (size_t)K * 64);
+    unsigned long long *s_close = s_kept + K;
+    unsigned long long *s_base = s_close + K;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_base + 1);
+    uint32_t *s_qpix = s_cnt + 2;
+    uint16_t *s_qd = reinterpret_cast<uint16_t *>(s_qpix + kTile);
+
     const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
-    const uint32_t ntiles = (npx + kTile - 1) / kTile;
-    unsigned c_gather = 0, c_hit = 0, c_acc = 0, c_after = 0;
-    uint32_t qn = 0;  // wave-uniform queue fill
-    for (uint32_t tile = blockIdx.x;; tile += gridDim.x) {
-        const bool more = tile < ntiles;
-        if (more) {
-            const uint32_t i0 = tile * kTile + lane * kPxPerLane;
-            uint16_t d[kPxPerLane];
-            uint8_t mk[kPxPerLane];
-            if (i0 + kPxPerLane <= npx) {
-                const ushort4 dv = *reinterpret_cast<const ushort4 *>(F.depth + i0);
-                const uchar4 mv = *reinterpret_cast<const uchar4 *>(F.mask + i0);
-                d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
-                mk[0] = mv.x; mk[1] = mv.y; mk[2] = mv.z; mk[3] = mv.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < kPxPerLane; j++) {
-                    const bool in = i0 + j < npx;
-                    d[j] = in ? F.depth[i0 + j] : (uint16_t)0;
-                    mk[j] = in ? F.mask[i0 + j] : (uint8_t)255;
-                }
-            }
-            // ballot / popcount compaction of live pixels (:100-101)
-            uint32_t off = qn;
+    const uint32_t shard = blockIdx.x % kListShards;
+
+    // -- tile load + ballot/popcount compaction of live pixels (:100-101).  Every wave builds
+    //    the same queue (identical values to identical LDS addresses): no barrier needed.
+    uint32_t qn = 0;
+    {
+        const uint32_t i0 = blockIdx.x * kTile + lane * kPxPerLane;
+        uint16_t d[kPxPerLane];
+        uint8_t mk[kPxPerLane];
+        if (i0 + kPxPerLane <= npx) {
+            const ushort4 dv = *reinterpret_cast<const ushort4 *>(F.depth + i0);
+            const uchar4 mv = *reinterpret_cast<const uchar4 *>(F.mask + i0);
+            d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
+            mk[0] = mv.x; mk[1] = mv.y; mk[2] = mv.z; mk[3] = mv.w;
+        } else {
 #pragma unroll
             for (int j = 0; j < kPxPerLane; j++) {
-                const bool live = (mk[j] == 0) && (d[j] > 0);
-                const unsigned long long m = __ballot(live);
-                if (live) s_queue[off + (unsigned)__popcll(m & lanemask_lt())] = i0 + j;
-                off += (unsigned)__popcll(m);
+                const bool in = i0 + j < npx;
+                d[j] = in ? F.depth[i0 + j] : (uint16_t)0;
+                mk[j] = in ? F.mask[i0 + j] : (uint8_t)255;
             }
-            qn = off;
         }
-        __syncthreads();
-        // dense batches of 64; the ragged remainder only once, after the last tile
-        while (qn >= (uint32_t)kWave || (!more && qn > 0)) {
-            const uint32_t take = qn < (uint32_t)kWave ? qn : (uint32_t)kWave;
-            qn -= take;
-            const bool act = lane < take;
-            const uint32_t pix = act ? s_queue[qn + lane] : 0u;
-            process_batch(frames, nbr_idx, a, F, pix, act, s_hits, c_gather, c_hit, c_acc, c_after);
+#pragma unroll
+        for (int j = 0; j < kPxPerLane; j++) {
+            const bool live = (mk[j] == 0) && (d[j] > 0) && (K > 0);  // K==0: :180 rejects all
+            const unsigned long long m = __ballot(live);
+            if (live) {
+                const unsigned pos = qn + (unsigned)__popcll(m & lanemask_lt());
+                s_qpix[pos] = i0 + j;
+                s_qd[pos] = d[j];
+            }
+            qn += (unsigned)__popcll(m);
         }
-        __syncthreads();
-        if (!more) break;
     }
-    c_gather = wave_sum(c_gather);
-    c_hit = wave_sum(c_hit);
-    c_acc = wave_sum(c_acc);
-    c_after = wave_sum(c_after);
-    if (lane == 0) {
-        if (c_gather) atomicAdd(&a.ctr->n_gather, (unsigned long long)c_gather);
-        if (c_hit) atomicAdd(&a.ctr->n_hit, (unsigned long long)c_hit);
-        if (c_acc) atomicAdd(&a.frame_before[a.f], (unsigned long long)c_acc);
-        if (c_after) atomicAdd(&a.frame_after[a.f], (unsigned long long)c_after);
+    if (w == 0 && lane == 0) {
+        s_cnt[0] = 0;
+        s_cnt[1] = 0;
+        // one reservation per workgroup: an entry per live pixel, issued early so its latency
+        // hides under the arithmetic below
+        *s_base = qn ? atomicAdd(&a.list.cursor[shard * 8], (unsigned long long)qn) : 0ull;
+    }
+    __syncthreads();
+
+    for (uint32_t c0 = 0; c0 < qn; c0 += kWave) {
+        const bool act = c0 + lane < qn;
+        const uint32_t pix = act ? s_qpix[c0 + lane] : 0u;
+        const double dsrc = act ? (double)s_qd[c0 + lane] : 1.0;
+        const int u = (int)(pix % (uint32_t)F.W);
+        const int v = (int)(pix / (uint32_t)F.W);
+        // phase 1 (every wave, redundantly): covariance gate + back-projection
+        bool ok = act;
+        const double tr = cov_trace(P, u, v, dsrc, F.K[0]);              // :136
+        if (tr > P.T_cov) ok = false;                                    // :138
+        const double xn = ((double)u - F.K[2]) / F.K[0];                 // pinhole.cpp:12
+        const double yn = ((double)v - F.K[3]) / F.K[1];
+        const double pcx = xn * dsrc, pcy = yn * dsrc, pcz = dsrc;       // :15-19
+        const double pwx = row_apply(F.Twk, 0, pcx, pcy, pcz);           // :144
+        const double pwy = row_apply(F.Twk, 1, pcx, pcy, pcz);
+        const double pwz = row_apply(F.Twk, 2, pcx, pcy, pcz);
+        uint32_t col = 0;
+        if (w == 0 && act) {                                             // :170, features.cpp:76-80
+            const uint8_t *cp = F.bgr + 3ull * pix;
+            col = (uint32_t)cp[0] | ((uint32_t)cp[1] << 8) | ((uint32_t)cp[2] << 16);
+        }
+        // phase 2: wave w re-observes the pixel in neighbours w, w+NW, ...  (:187-216)
+        unsigned n_gather = 0;
+        for (uint32_t k = w; k < K; k += NW) {
+            const uint32_t nb = nbr_idx[F.nbr_begin + k];
+            const FrameDev &L = frames[nb];
+            bool kept = false, close = false, vis = false;
+            if (ok) {
+                // KeyFrame::point_in_frame, keyframe.cpp:275-294 / pinhole.cpp:32-45
+                const double cx_ = row_apply(L.Tkw, 0, pwx, pwy, pwz);
+                const double cy_ = row_apply(L.Tkw, 1, pwx, pwy, pwz);
+                const double cz_ = row_apply(L.Tkw, 2, pwx, pwy, pwz);
+                const double px = (cx_ / cz_) * L.K[0] + L.K[2];
+                const double py = (cy_ / cz_) * L.K[1] + L.K[3];
+                // NaN projections are "not visible" (UB in the reference): hence the >= 0 form
+                vis = (px >= 0) && (px < (double)L.W) && (py >= 0) && (py < (double)L.H) && !(cz_ < 0);
+                if (vis) {
+                    const int ix = (int)floor(px);
+                    const int iy = (int)floor(py);
+                    const uint32_t npix = (uint32_t)iy * (uint32_t)L.W + (uint32_t)ix;
+                    const double d = (double)L.depth[npix];              // :193 (no d>0 test)
+                    const double x = ((double)ix - L.K[2]) / L.K[0];
+                    const double y = ((double)iy - L.K[3]) / L.K[1];
+                    const double qcx = x * d, qcy = y * d, qcz = d;
+                    const double qx = row_apply(L.Twk, 0, qcx, qcy, qcz);
+                    const double qy = row_apply(L.Twk, 1, qcx, qcy, qcz);
+                    const double qz = row_apply(L.Twk, 2, qcx, qcy, qcz);
+                    const double wgt = cov_trace(P, ix, iy, d, L.K[0]);  // :202
+                    if (wgt < P.T_cov) {                                 // :204
+                        kept = true;
+                        const double dx = qx - pwx, dy = qy - pwy, dz = qz - pwz;
+                        const double s = (dx * dx + dy * dy) + dz * dz;  // norm(): (e0+e1)+e2
+                        close = s < P.tau_dist2;                         // :224
+                        const double inv = 1.0 / wgt;                    // :161-162
+                        double *o = s_obs + (size_t)k * 256 + lane;
+                        o[0] = qx * inv;
+                        o[64] = qy * inv;
+                        o[128] = qz * inv;
+                        o[192] = inv;
+                        s_hit[k * 64 + lane] = npix;
+                    }
+                }
+            }
+            const unsigned long long mk_ = __ballot(kept);
+            const unsigned long long mc_ = __ballot(close);
+            n_gather += (unsigned)__popcll(__ballot(vis));
+            if (lane == 0) {
+                s_kept[k] = mk_;
+                s_close[k] = mc_;
+            }
+        }
+        if (lane == 0 && n_gather) atomicAdd(&s_cnt[0], n_gather);
+        __syncthreads();
+        // phase 3 (wave 0): decision, mask scatter, weighted fusion, record
+        if (w == 0) {
+            unsigned n_obs = 0, n_close = 0;
+            double wx = 0, wy = 0, wz = 0, total = 0;
+            for (uint32_t k = 0; k < K; k++) {                           // neighbour order, :160-163
+                if ((s_kept[k] >> lane) & 1ull) {
+                    n_obs++;
+                    n_close += (unsigned)((s_close[k] >> lane) & 1ull);
+                    const double *o = s_obs + (size_t)k * 256 + lane;
+                    wx = wx + o[0];
+                    wy = wy + o[64];
+                    wz = wz + o[128];
+                    total = total + o[192];
+                }
+            }
+            if (n_obs < 1) ok = false;                                       // :218
+            if ((double)n_close < (double)n_obs * P.close_frac) ok = false;  // :229
+            unsigned c_hit = 0;
+            unsigned long long key = 0, tag = kEmpty;
+            double fx = 0, fy = 0, fz = 0;
+            if (ok) {
+                for (uint32_t k = 0; k < K; k++) {                           // :152-154
+                    if ((s_kept[k] >> lane) & 1ull) {
+                        c_hit++;
+                        const uint32_t nb = nbr_idx[F.nbr_begin + k];
+                        // masks of already-processed keyframes are never read again
+                        if (nb > a.f) frames[nb].mask[s_hit[k * 64 + lane]] = 255;
+                    }
+                }
+                fx = wx / total; fy = wy / total; fz = wz / total;           // :164
+                unsigned long long c0_, c1_, c2_;
+                const int fits = (int)axis_code(voxel_index(fx, P.voxel_size), c0_) &
+                                 (int)axis_code(voxel_index(fy, P.voxel_size), c1_) &
+                                 (int)axis_code(voxel_index(fz, P.voxel_size), c2_);
+                if (fits) {
+                    key = (c0_ << 42) | (c1_ << 21) | c2_;
+                    tag = ((unsigned long long)F.order << 32) | pix;
+                } else {
+                    atomicOr(&a.stat[blockIdx.x % kStatShards].err, kErrKeyRange);
+                }
+            }
+            if (act) {
+                const unsigned long long rel = *s_base + c0 + lane;
+                if (rel < a.list.shard_cap) {
+                    const unsigned long long idx = (unsigned long long)shard * a.list.shard_cap + rel;
+                    a.list.tag[idx] = tag;
+                    if (tag != kEmpty) {
+                        a.list.key[idx] = key;
+                        a.list.xyz[3 * idx + 0] = fx;
+                        a.list.xyz[3 * idx + 1] = fy;
+                        a.list.xyz[3 * idx + 2] = fz;
+                        a.list.bgr[idx] = col;
+                    }
+                } else {
+                    atomicOr(&a.stat[blockIdx.x % kStatShards].err, kErrListFull);
+                }
+            }
+            c_hit = wave_sum(c_hit);
+            if (lane == 0) s_cnt[1] += c_hit;
+        }
+        if (c0 + kWave < qn) __syncthreads();  // s_obs/s_kept are reused by the next chunk
+    }
+
+    if (w == 0) {
+        unsigned last = 0;
+        if (lane == 0) {
+            StatShard *st = &a.stat[blockIdx.x % kStatShards];
+            if (s_cnt[0]) atomicAdd(&st->n_gather, (unsigned long long)s_cnt[0]);
+            if (s_cnt[1]) atomicAdd(&st->n_hit, (unsigned long long)s_cnt[1]);
+            // this workgroup's cursor reservation has returned (s_base was read above)
+            last = atomicAdd(&a.frame_done[a.f], 1u) == gridDim.x - 1;
+        }
+        last = __shfl(last, 0);
+        if (last && lane < kListShards)
+            a.list.frame_end[(size_t)a.f * kListShards + lane] =
+                atomicAdd(&a.list.cursor[lane * 8], 0ull);
+    }
+}
+
+// ---- voxel table: first-wins filter for a group of keyframes ------------------------------
+
+struct TableArgs {
+    Slot *table;
+    unsigned long long *mark;  // per slot: (group+1) << 32 | bitmask of the group's keyframes seen
+    uint64_t table_mask;       // capacity-1
+    ListDev list;
+    Counters *ctr;
+    unsigned long long *frame_before;  // [n_frames] "Points before voxel filter" (:118)
+    unsigned long long *frame_after;   // [n_frames] "Points after voxel filter"  (:120)
+    uint32_t f0, f1;                   // keyframes [f0, f1), f1 - f0 <= kGroup
+    uint32_t group;
+};
+
+// For every accepted record of keyframes [f0,f1): claim/find the voxel's slot (atomicCAS on
+// the key), lower its tag (atomicMin == first-wins per frame and globally,
+// dense_reconstruction.cpp:283-287 applied at :119 and :57), and count the voxels each
+// keyframe touches (= size of its per-frame filter output).  Stale plain reads are safe:
+// keys never change once set, tags only decrease, mark bits only accumulate within a group.
+__global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
+{
+    __shared__ unsigned int s_before[kGroup], s_after[kGroup];
+    __shared__ unsigned int s_claims, s_maxprobe, s_err;
+    if (threadIdx.x < kGroup) { s_before[threadIdx.x] = 0; s_after[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) { s_claims = 0; s_maxprobe = 0; s_err = 0; }
+    __syncthreads();
+    const uint32_t shard = blockIdx.y;
+    const unsigned long long begin = a.f0 ? a.list.frame_end[(size_t)(a.f0 - 1) * kListShards + shard] : 0ull;
+    unsigned long long end = a.list.frame_end[(size_t)(a.f1 - 1) * kListShards + shard];
+    if (end > a.list.shard_cap) end = a.list.shard_cap;
+    const unsigned long long base = (unsigned long long)shard * a.list.shard_cap;
+    const unsigned long long want_hi = (unsigned long long)a.group + 1ull;
+    unsigned claims = 0, maxprobe = 0;
+    for (unsigned long long i = begin + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < end;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long tag = a.list.tag[base + i];
+        if (tag == kEmpty) continue;
+        const unsigned long long key = a.list.key[base + i];
+        const uint32_t fr = (uint32_t)(tag >> 32) - a.f0;
+        atomicAdd(&s_before[fr], 1u);
+        uint64_t h = mix64(key) & a.table_mask;
+        unsigned probes = 0;
+        bool found = false;
+        for (;;) {
+            unsigned long long cur = a.table[h].key;
+            if (cur == kEmpty) {
+                cur = atomicCAS(&a.table[h].key, kEmpty, key);
+                if (cur == kEmpty) { claims++; cur = key; }
+            }
+            if (cur == key) { found = true; break; }
+            h = (h + 1) & a.table_mask;
+            if (++probes > 4096u || probes > a.table_mask) break;
+        }
+        if (!found) { s_err = kErrTableFull; continue; }
+        if (probes > maxprobe) maxprobe = probes;
+        if (a.table[h].tag > tag) atomicMin(&a.table[h].tag, tag);
+        const unsigned long long bit = 1ull << fr;
+        unsigned long long old = a.mark[h];
+        for (;;) {
+            const bool same = (old >> 32) == want_hi;
+            if (same && (old & bit)) break;
+            const unsigned long long neu = same ? (old | bit) : ((want_hi << 32) | bit);
+            const unsigned long long prev = atomicCAS(&a.mark[h], old, neu);
+            if (prev == old) { atomicAdd(&s_after[fr], 1u); break; }
+            old = prev;
+        }
+    }
+    if (claims) atomicAdd(&s_claims, claims);
+    if (maxprobe) atomicMax(&s_maxprobe, maxprobe);
+    __syncthreads();
+    if (threadIdx.x < kGroup && a.f0 + threadIdx.x < a.f1) {
+        if (s_before[threadIdx.x]) atomicAdd(&a.frame_before[a.f0 + threadIdx.x], (unsigned long long)s_before[threadIdx.x]);
+        if (s_after[threadIdx.x]) atomicAdd(&a.frame_after[a.f0 + threadIdx.x], (unsigned long long)s_after[threadIdx.x]);
+    }
+    if (threadIdx.x == 0) {
+        if (s_claims) atomicAdd(&a.ctr->table_used, (unsigned long long)s_claims);
+        if (s_maxprobe > a.ctr->max_probe) atomicMax(&a.ctr->max_probe, s_maxprobe);
+        if (s_err) atomicOr(&a.ctr->err, s_err);
     }
 }
 
@@ -398,11 +478,7 @@ __global__ __launch_bounds__(64) void fuse_frame_kernel(const FrameDev *__restri
 struct FinalizeArgs {
     const Slot *table;
     uint64_t table_mask;
-    const unsigned long long *list_key;
-    const unsigned long long *list_tag;
-    const double *list_xyz;
-    const uint32_t *list_bgr;
-    uint64_t n_list;
+    ListDev list;
     Counters *ctr;
     // output (SoA, device)
     double *out_xyz;
@@ -411,38 +487,42 @@ struct FinalizeArgs {
     unsigned long long *out_tag;
 };
 
-// A list entry is an output point iff its tag is the minimum recorded for its voxel.
+// A record is an output point iff its tag is the minimum recorded for its voxel.
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
 {
     const unsigned lane = lane_id();
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t n_round = (a.n_list + 63) / 64 * 64;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    const uint32_t shard = blockIdx.y;
+    unsigned long long end = a.list.cursor[shard * 8];
+    if (end > a.list.shard_cap) end = a.list.shard_cap;
+    const unsigned long long base = (unsigned long long)shard * a.list.shard_cap;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long n_round = (end + 63) / 64 * 64;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         bool win = false;
-        unsigned long long key = 0, tag = 0;
-        if (i < a.n_list) {
-            key = a.list_key[i];
-            tag = a.list_tag[i];
+        unsigned long long key = 0, tag = kEmpty;
+        if (i < end) tag = a.list.tag[base + i];
+        if (tag != kEmpty) {
+            key = a.list.key[base + i];
             uint64_t h = mix64(key) & a.table_mask;
             for (;;) {
                 const unsigned long long cur = a.table[h].key;
                 if (cur == key) { win = a.table[h].tag == tag; break; }
-                if (cur == kEmpty) break;  // cannot happen: every listed key was inserted
+                if (cur == kEmpty) break;  // cannot happen: every accepted key was inserted
                 h = (h + 1) & a.table_mask;
             }
         }
         const unsigned long long m = __ballot(win);
         if (m != 0) {
-            unsigned long long base = 0;
+            unsigned long long obase = 0;
             const int leader = __ffsll((long long)m) - 1;
-            if ((int)lane == leader) base = atomicAdd(&a.ctr->out_count, (unsigned long long)__popcll(m));
-            base = __shfl(base, leader);
+            if ((int)lane == leader) obase = atomicAdd(&a.ctr->out_count, (unsigned long long)__popcll(m));
+            obase = __shfl(obase, leader);
             if (win) {
-                const unsigned long long o = base + (unsigned)__popcll(m & lanemask_lt());
-                a.out_xyz[3 * o + 0] = a.list_xyz[3 * i + 0];
-                a.out_xyz[3 * o + 1] = a.list_xyz[3 * i + 1];
-                a.out_xyz[3 * o + 2] = a.list_xyz[3 * i + 2];
-                a.out_bgr[o] = a.list_bgr[i];
+                const unsigned long long o = obase + (unsigned)__popcll(m & lanemask_lt());
+                a.out_xyz[3 * o + 0] = a.list.xyz[3 * (base + i) + 0];
+                a.out_xyz[3 * o + 1] = a.list.xyz[3 * (base + i) + 1];
+                a.out_xyz[3 * o + 2] = a.list.xyz[3 * (base + i) + 2];
+                a.out_bgr[o] = a.list.bgr[base + i];
                 a.out_key[o] = key;
                 a.out_tag[o] = tag;
             }
