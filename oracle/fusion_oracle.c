@@ -92,6 +92,8 @@ typedef struct {
     uint64_t global_after;  /* "Points after voxel removal"  (:58) */
     /* traffic counters for the roofline's algorithmic byte count */
     uint64_t n_px, n_gather, n_acc, n_hit, n_vox;
+    /* where live pixels end: diagnostic split of the rejections */
+    uint64_t n_live, n_rej_cov, n_rej_noobs, n_rej_far;
 } orc_result;
 
 void orc_default_params(orc_params *p)
@@ -229,7 +231,7 @@ typedef struct {
 } point_rec;
 
 typedef struct {
-    uint64_t n_gather, n_hit;
+    uint64_t n_gather, n_hit, n_live, n_rej_cov, n_rej_noobs, n_rej_far;
 } px_counters;
 
 static inline uint16_t depth_at(const orc_frame *f, int x, int y)
@@ -247,13 +249,14 @@ static int process_pixel(const orc_params *P, const orc_frame *frames, uint8_t *
     const orc_frame *f = &frames[fi];
     uint16_t depth = depth_at(f, u, v);
     if (depth <= 0) return 0;                                        /* :132 */
+    ctr->n_live++;
     double tr = orc_cov_trace(P, u, v, (double)depth, f->K[0]);      /* :136 */
-    if (tr > P->T_cov) return 0;                                     /* :138 */
+    if (tr > P->T_cov) { ctr->n_rej_cov++; return 0; }               /* :138 */
     double pc[3], pw[3];
     orc_deproject(f->K, u, v, (double)depth, pc);                    /* :143 */
     mat4_apply(f->T_wk, pc, pw);                                     /* :144 */
 
-    if (n_nb == 0) return 0;                                         /* :180 */
+    if (n_nb == 0) { ctr->n_rej_noobs++; return 0; }                 /* :180 */
     uint32_t n_obs = 0;
     for (uint32_t k = 0; k < n_nb; k++) {                            /* :187 */
         const orc_frame *lf = &frames[nb[k]];
@@ -275,7 +278,7 @@ static int process_pixel(const orc_params *P, const orc_frame *frames, uint8_t *
             n_obs++;
         }
     }
-    if (n_obs < 1) return 0;                                         /* :218 */
+    if (n_obs < 1) { ctr->n_rej_noobs++; return 0; }                 /* :218 */
     uint64_t close_count = 0;
     for (uint32_t i = 0; i < n_obs; i++) {                           /* :223 */
         double dx = obs_p[3 * i + 0] - pw[0];
@@ -284,7 +287,7 @@ static int process_pixel(const orc_params *P, const orc_frame *frames, uint8_t *
         double n = sqrt((dx * dx + dy * dy) + dz * dz);
         if (n < P->T_dist) close_count++;
     }
-    if ((double)close_count < (double)n_obs * P->close_frac) return 0; /* :229 */
+    if ((double)close_count < (double)n_obs * P->close_frac) { ctr->n_rej_far++; return 0; } /* :229 */
 
     for (uint32_t i = 0; i < n_obs; i++) {                           /* :152-154 */
         masks[obs_frame[i]][obs_pix[i]] = 255;
@@ -433,13 +436,17 @@ int orc_fuse(const orc_params *P, const orc_frame *frames, uint32_t n_frames, in
             j->P = P; j->frames = frames; j->masks = masks; j->fi = fi; j->nb = nb; j->n_nb = n_nb;
             j->row0 = (int)((int64_t)f->H * t / nt);
             j->row1 = (int)((int64_t)f->H * (t + 1) / nt);
-            j->got = got; j->local = local; j->ctr.n_gather = 0; j->ctr.n_hit = 0;
+            j->got = got; j->local = local; memset(&j->ctr, 0, sizeof j->ctr);
             if (nt == 1) job_run(j); else pthread_create(&th[t], NULL, job_run, j);
         }
         for (int t = 0; t < nt; t++) {
             if (nt > 1) pthread_join(th[t], NULL);
             out->n_gather += jobs[t].ctr.n_gather;
             out->n_hit += jobs[t].ctr.n_hit;
+            out->n_live += jobs[t].ctr.n_live;
+            out->n_rej_cov += jobs[t].ctr.n_rej_cov;
+            out->n_rej_noobs += jobs[t].ctr.n_rej_noobs;
+            out->n_rej_far += jobs[t].ctr.n_rej_far;
         }
         uint64_t n_f = 0;
         for (uint64_t i = 0; i < px; i++)                            /* :112-116 raster order */

@@ -62,6 +62,10 @@ class OrcResult(C.Structure):
         ("n_acc", C.c_uint64),
         ("n_hit", C.c_uint64),
         ("n_vox", C.c_uint64),
+        ("n_live", C.c_uint64),
+        ("n_rej_cov", C.c_uint64),
+        ("n_rej_noobs", C.c_uint64),
+        ("n_rej_far", C.c_uint64),
     ]
 
 
@@ -218,7 +222,9 @@ def fuse(frames, params=None, n_threads: int = 1) -> Cloud:
         xyz, bgr, key, tag = sort_by_key(xyz, bgr, key, tag)
         return Cloud(xyz, bgr, key, tag, fb, fa, int(res.global_before), int(res.global_after),
                      dict(n_px=int(res.n_px), n_gather=int(res.n_gather), n_acc=int(res.n_acc),
-                          n_hit=int(res.n_hit), n_vox=int(res.n_vox)))
+                          n_hit=int(res.n_hit), n_vox=int(res.n_vox), n_live=int(res.n_live),
+                          n_rej_cov=int(res.n_rej_cov), n_rej_noobs=int(res.n_rej_noobs),
+                          n_rej_far=int(res.n_rej_far)))
     finally:
         lib().orc_free_result(C.byref(res))
 

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -59,22 +60,24 @@ struct sfm_fusion_ctx {
     std::vector<HostFrame> frames;
     bool layout_dirty = true;
 
-    DevBuf<FrameDev> d_frames;
-    DevBuf<uint32_t> d_nbr;
+    DevBuf<FrameDev> d_nbrpack;      // per keyframe: a FrameDev copy of each filtered neighbour
+    std::vector<FrameDev> h_frames;  // device-side description of every keyframe (host copy)
     DevBuf<uint8_t> d_masks;
     DevBuf<Slot> d_table;
     DevBuf<unsigned long long> d_mark;
     DevBuf<unsigned long long> d_list_key, d_list_tag, d_out_key, d_out_tag;
     DevBuf<double> d_list_xyz, d_out_xyz;
     DevBuf<uint32_t> d_list_bgr, d_out_bgr;
-    DevBuf<unsigned long long> d_fbefore, d_fafter, d_frame_end;
-    DevBuf<unsigned int> d_frame_done;
+    DevBuf<unsigned long long> d_fbefore, d_fafter, d_group_end;
     // one allocation: Counters | cursors | stat shards (zeroed by a single memset per run)
     unsigned char *d_small = nullptr;
     HostCounters *h_small = nullptr;  // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_init = nullptr, ev_b_done = nullptr;
     std::vector<hipEvent_t> gev;  // one per keyframe group
+    unsigned long long *stamp_dev = nullptr;
+    uint32_t stamp_tiles = 0;
+    uint32_t max_waves = 4;          // waves per fuse_frame workgroup (SFM_FUSE_WAVES overrides)
     bool profile = false;         // per-launch start/stop events on the frame kernels
     std::vector<hipEvent_t> kev;  // 2 per keyframe when profiling
 
@@ -185,7 +188,8 @@ int build_layout(sfm_fusion_ctx *c)
     for (auto &f : c->frames) c->total_px += (uint64_t)f.W * f.H;
     int rc;
     if ((rc = ensure(c, c->d_masks, total))) return rc;
-    std::vector<FrameDev> fd(n);
+    std::vector<FrameDev> &fd = c->h_frames;
+    fd.assign(n, FrameDev());
     std::vector<uint32_t> nbr;
     for (size_t i = 0; i < n; i++) {
         HostFrame &f = c->frames[i];
@@ -211,15 +215,14 @@ int build_layout(sfm_fusion_ctx *c)
                             " filtered neighbours; the kernels handle at most " +
                             std::to_string(SFM_MAX_NEIGHBORS));
     }
-    if ((rc = ensure(c, c->d_frames, n))) return rc;
-    if ((rc = ensure(c, c->d_nbr, nbr.size()))) return rc;
+    std::vector<FrameDev> pack(nbr.size());
+    for (size_t j = 0; j < nbr.size(); j++) pack[j] = fd[nbr[j]];
+    if ((rc = ensure(c, c->d_nbrpack, pack.size()))) return rc;
     if ((rc = ensure(c, c->d_fbefore, n))) return rc;
     if ((rc = ensure(c, c->d_fafter, n))) return rc;
-    if ((rc = ensure(c, c->d_frame_end, n * kListShards))) return rc;
-    if ((rc = ensure(c, c->d_frame_done, n))) return rc;
-    if (n) HIP_TRY(c, hipMemcpy(c->d_frames.p, fd.data(), n * sizeof(FrameDev), hipMemcpyHostToDevice));
-    if (!nbr.empty())
-        HIP_TRY(c, hipMemcpy(c->d_nbr.p, nbr.data(), nbr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if ((rc = ensure(c, c->d_group_end, (n + kGroup - 1) / kGroup * kListShards * 8))) return rc;
+    if (!pack.empty())
+        HIP_TRY(c, hipMemcpy(c->d_nbrpack.p, pack.data(), pack.size() * sizeof(FrameDev), hipMemcpyHostToDevice));
     c->layout_dirty = false;
     return SFM_OK;
 }
@@ -257,8 +260,6 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     if (n) {
         HIP_TRY(c, hipMemsetAsync(c->d_fbefore.p, 0, n * sizeof(unsigned long long), sa));
         HIP_TRY(c, hipMemsetAsync(c->d_fafter.p, 0, n * sizeof(unsigned long long), sa));
-        HIP_TRY(c, hipMemsetAsync(c->d_frame_done.p, 0, n * sizeof(unsigned int), sa));
-        HIP_TRY(c, hipMemsetAsync(c->d_frame_end.p, 0, n * kListShards * sizeof(unsigned long long), sa));
     }
     HIP_TRY(c, hipEventRecord(c->ev_init, sa));
     HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_init, 0));
@@ -270,11 +271,10 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     list.bgr = c->d_list_bgr.p;
     list.shard_cap = shard_cap;
     list.cursor = dev_cursor(c);
-    list.frame_end = c->d_frame_end.p;
+    list.group_end = c->d_group_end.p;
 
     FuseArgs a;
     a.list = list;
-    a.frame_done = c->d_frame_done.p;
     a.stat = dev_stat(c);
     a.P.base_line = c->prm.base_line;
     a.P.T_cov = c->prm.T_cov;
@@ -302,18 +302,35 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
         // a keyframe without pixels still runs one (empty) workgroup so that its list
         // boundary frame_end[] is published
         const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, (px + kTile - 1) / kTile);
-        const uint32_t nw = std::min<uint32_t>(std::max<uint32_t>(f.n_filtered, 1), kMaxWaves);
+        const uint32_t nw = std::min<uint32_t>(std::max<uint32_t>(f.n_filtered, 1), c->max_waves);
         const size_t lds = fuse_lds_bytes(f.n_filtered);
         a.f = (uint32_t)i;
+        a.F = c->h_frames[i];
+#ifdef SFM_STAMPS
+        {   // diagnostic build: stamp one keyframe's workgroups and dump them after the run
+            static unsigned long long *d_st = nullptr;
+            const char *sf = std::getenv("SFM_STAMP_FRAME");
+            a.stamps = nullptr;
+            if (sf && (size_t)std::atoi(sf) == i) {
+                if (!d_st) (void)hipMalloc(&d_st, 8 * 8 * 65536);
+                (void)hipMemsetAsync(d_st, 0, 8 * 8 * 65536, sa);
+                a.stamps = d_st;
+                c->stamp_dev = d_st;
+                c->stamp_tiles = tiles;
+            }
+        }
+#endif
+        const FrameDev *nbp = c->d_nbrpack.p + a.F.nbr_begin;
         if (c->profile)
             hipExtLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(nw * kWave), lds, sa, c->kev[2 * i],
-                                  c->kev[2 * i + 1], 0, (const FrameDev *)c->d_frames.p,
-                                  (const uint32_t *)c->d_nbr.p, a);
+                                  c->kev[2 * i + 1], 0, nbp, a);
         else
-            hipLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(nw * kWave), lds, sa,
-                               (const FrameDev *)c->d_frames.p, (const uint32_t *)c->d_nbr.p, a);
+            hipLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(nw * kWave), lds, sa, nbp, a);
         if (i % kGroup == kGroup - 1 || i + 1 == n) {
             const size_t g = i / kGroup;
+            // list boundaries of the group: snapshot of the append cursors, in stream order
+            HIP_TRY(c, hipMemcpyAsync(c->d_group_end.p + g * kListShards * 8, dev_cursor(c),
+                                      kListShards * 8 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, sa));
             HIP_TRY(c, hipEventRecord(c->gev[g], sa));
             HIP_TRY(c, hipStreamWaitEvent(sb, c->gev[g], 0));
             t.f0 = (uint32_t)(g * kGroup);
@@ -359,6 +376,16 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     HIP_TRY(c, hipEventRecord(c->ev[3], sa));
     HIP_TRY(c, hipMemcpyAsync(c->h_small, c->d_small, kSmallBytes, hipMemcpyDeviceToHost, sa));
     HIP_TRY(c, hipStreamSynchronize(sa));
+#ifdef SFM_STAMPS
+    if (c->stamp_dev && std::getenv("SFM_STAMP_FILE")) {
+        std::vector<unsigned long long> h((size_t)c->stamp_tiles * 8);
+        (void)hipMemcpy(h.data(), c->stamp_dev, h.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE *fp = std::fopen(std::getenv("SFM_STAMP_FILE"), "wb")) {
+            std::fwrite(h.data(), 8, h.size(), fp);
+            std::fclose(fp);
+        }
+    }
+#endif
     return SFM_OK;
 }
 
@@ -395,6 +422,10 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
     if (!c) return SFM_E_NOMEM;
     if (params) c->prm = *params; else sfm_fusion_default_params(&c->prm);
     c->device = device;
+    if (const char *e = std::getenv("SFM_FUSE_WAVES")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= kMaxWaves) c->max_waves = (uint32_t)v;
+    }
     std::memset(&c->stats, 0, sizeof c->stats);
     bool ok = hipSetDevice(device) == hipSuccess;
     if (ok && stream) {
@@ -427,11 +458,10 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
         if (f.d_depth) (void)hipFree(f.d_depth);
         if (f.d_bgr) (void)hipFree(f.d_bgr);
     }
-    release(c->d_frames); release(c->d_nbr); release(c->d_masks); release(c->d_table);
+    release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
     release(c->d_mark); release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
-    release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_frame_end);
-    release(c->d_frame_done);
+    release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_group_end);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto &e : c->ev)

@@ -14,6 +14,9 @@
 //                       second stream, off the keyframe chain.
 //   finalize_kernel     gathers the winners into the output cloud.
 #pragma once
+#ifndef SFM_ABLATE_EXIT
+#define SFM_ABLATE_EXIT 0
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -82,16 +85,31 @@ struct ListDev {
     uint32_t *bgr;           // b | g<<8 | r<<16
     uint64_t shard_cap;
     unsigned long long *cursor;     // [kListShards * 8]  (stride 8 => one line per cursor)
-    unsigned long long *frame_end;  // [n_frames * kListShards] cursor values after each keyframe
+    // [n_groups][kListShards * 8]: copy of cursor[] taken on the keyframe stream after the last
+    // keyframe of each group (a 1-KiB device-to-device copy), i.e. the groups' list boundaries
+    const unsigned long long *group_end;
 };
 
 struct FuseArgs {
+    FrameDev F;                // the keyframe being fused (by value: arrives with the kernargs)
     ListDev list;
-    unsigned int *frame_done;  // [n_frames] finished workgroups
     StatShard *stat;           // [kStatShards]
     DevParams P;
     uint32_t f;
+#ifdef SFM_STAMPS
+    unsigned long long *stamps;  // diagnostic build only: [tiles][8] s_memrealtime values
+#endif
 };
+
+#ifdef SFM_STAMPS
+#define SFM_STAMP(i)                                                                   \
+    do {                                                                               \
+        if (a.stamps && (w == 0 || (i) == 5) && lane == 0)                             \
+            a.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define SFM_STAMP(i) do {} while (0)
+#endif
 
 // ---- exact arithmetic helpers ---------------------------------------------------------
 
@@ -166,41 +184,59 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 
 // ---- the per-keyframe kernel ------------------------------------------------------------
 //
+// Workgroup = one 256-pixel tile, NW waves.  Stages:
+//   A  every wave: coalesced tile load + ballot/popcount compaction of live pixels into s_q
+//   B  live chunks dealt round-robin to the waves: covariance gate + back-projection; the
+//      survivors are re-compacted into s_q2 (pixel, world point)
+//   C  per 64-survivor chunk: wave w re-observes the chunk in neighbours w, w+NW, ...;
+//      results meet in LDS; ONE wave (rotating with the workgroup id, so that the serial part
+//      spreads over the four SIMDs) takes the decision, scatters the masks and writes records.
+//
 // LDS per workgroup (dynamic, K = filtered neighbours of this keyframe):
 //   s_obs  [K][4][64] double   per neighbour, per lane: q*(1/w) (x,y,z) and 1/w
 //   s_hit  [K][64]    u32      re-observed pixel in the neighbour
 //   s_kept [K], s_close[K] u64 ballots: observation kept (:204) / within T_dist (:224)
-//   s_base u64, s_cnt[2] u32, s_qpix[256] u32, s_qd[256] u16   tile queue
+//   s_pw   [3][256]   double   world point of each survivor
+//   s_base u64, s_cnt[4] u32, s_qpix[256] u32, s_q2pix[256] u32, s_qd[256] u16
 __host__ __device__ inline size_t fuse_lds_bytes(uint32_t K)
 {
-    return (size_t)K * (4 * 64 * 8 + 64 * 4 + 16) + 8 + 8 + kTile * 4 + kTile * 2;
+    return (size_t)K * (4 * 64 * 8 + 64 * 4 + 16) + 3 * kTile * 8 + 8 + 16 + kTile * 4 + kTile * 4 + kTile * 2;
 }
 
 // process_pixel + geometric_check (dense_reconstruction.cpp:126-234).
+// nbp = this keyframe's filtered neighbours, one FrameDev copy each, in neighbour order
+// (never written by any kernel: __restrict__ keeps the reads on the scalar path).
 __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
-    const FrameDev *__restrict__ frames, const uint32_t *__restrict__ nbr_idx, FuseArgs a)
+    const FrameDev *__restrict__ nbp, FuseArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const unsigned lane = lane_id();
-    const unsigned w = threadIdx.x >> 6;
+    // wave index as a scalar: everything indexed by it stays wave-uniform (SGPRs, s_load)
+    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned NW = blockDim.x >> 6;
-    const FrameDev &F = frames[a.f];
+    const FrameDev &F = a.F;
     const DevParams &P = a.P;
     const uint32_t K = F.nbr_count;
     double *s_obs = reinterpret_cast<double *>(smem);
     uint32_t *s_hit = reinterpret_cast<uint32_t *>(s_obs + (size_t)K * 256);
     unsigned long long *s_kept = reinterpret_cast<unsigned long long *>(s_hit + (size_t)K * 64);
     unsigned long long *s_close = s_kept + K;
-    unsigned long long *s_base = s_close + K;
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_base + 1);
-    uint32_t *s_qpix = s_cnt + 2;
-    uint16_t *s_qd = reinterpret_cast<uint16_t *>(s_qpix + kTile);
+    double *s_pw = reinterpret_cast<double *>(s_close + K);
+    unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_pw + 3 * kTile);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_base + 1);  // [0] gathers [1] hits [2] survivors
+    uint32_t *s_qpix = s_cnt + 4;
+    uint32_t *s_q2pix = s_qpix + kTile;
+    uint16_t *s_qd = reinterpret_cast<uint16_t *>(s_q2pix + kTile);
 
     const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
     const uint32_t shard = blockIdx.x % kListShards;
+    SFM_STAMP(0);
+#if SFM_ABLATE_EXIT == 1
+    return;
+#endif
 
-    // -- tile load + ballot/popcount compaction of live pixels (:100-101).  Every wave builds
-    //    the same queue (identical values to identical LDS addresses): no barrier needed.
+    // -- stage A: tile load + ballot/popcount compaction of live pixels (:100-101).  Every wave
+    //    builds the same queue (identical values to identical LDS addresses).
     uint32_t qn = 0;
     {
         const uint32_t i0 = blockIdx.x * kTile + lane * kPxPerLane;
@@ -231,43 +267,72 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
             qn += (unsigned)__popcll(m);
         }
     }
+    SFM_STAMP(1);
+    if (qn == 0) return;  // uniform over the workgroup
     if (w == 0 && lane == 0) {
         s_cnt[0] = 0;
         s_cnt[1] = 0;
-        // one reservation per workgroup: an entry per live pixel, issued early so its latency
-        // hides under the arithmetic below
-        *s_base = qn ? atomicAdd(&a.list.cursor[shard * 8], (unsigned long long)qn) : 0ull;
+        s_cnt[2] = 0;
     }
     __syncthreads();
 
-    for (uint32_t c0 = 0; c0 < qn; c0 += kWave) {
+    // -- stage B: covariance gate + back-projection, chunks dealt to the waves
+    for (uint32_t c0 = w * kWave; c0 < qn; c0 += NW * kWave) {
         const bool act = c0 + lane < qn;
         const uint32_t pix = act ? s_qpix[c0 + lane] : 0u;
         const double dsrc = act ? (double)s_qd[c0 + lane] : 1.0;
         const int u = (int)(pix % (uint32_t)F.W);
         const int v = (int)(pix / (uint32_t)F.W);
-        // phase 1 (every wave, redundantly): covariance gate + back-projection
-        bool ok = act;
         const double tr = cov_trace(P, u, v, dsrc, F.K[0]);              // :136
-        if (tr > P.T_cov) ok = false;                                    // :138
-        const double xn = ((double)u - F.K[2]) / F.K[0];                 // pinhole.cpp:12
-        const double yn = ((double)v - F.K[3]) / F.K[1];
-        const double pcx = xn * dsrc, pcy = yn * dsrc, pcz = dsrc;       // :15-19
-        const double pwx = row_apply(F.Twk, 0, pcx, pcy, pcz);           // :144
-        const double pwy = row_apply(F.Twk, 1, pcx, pcy, pcz);
-        const double pwz = row_apply(F.Twk, 2, pcx, pcy, pcz);
-        uint32_t col = 0;
-        if (w == 0 && act) {                                             // :170, features.cpp:76-80
-            const uint8_t *cp = F.bgr + 3ull * pix;
-            col = (uint32_t)cp[0] | ((uint32_t)cp[1] << 8) | ((uint32_t)cp[2] << 16);
+        const bool pass = act && !(tr > P.T_cov);                        // :138
+        const unsigned long long m = __ballot(pass);
+        if (m != 0) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned base = 0;
+            if ((int)lane == leader) base = atomicAdd(&s_cnt[2], (unsigned)__popcll(m));
+            base = __shfl(base, leader);
+            if (pass) {
+                const double xn = ((double)u - F.K[2]) / F.K[0];         // pinhole.cpp:12
+                const double yn = ((double)v - F.K[3]) / F.K[1];
+                const double pcx = xn * dsrc, pcy = yn * dsrc, pcz = dsrc;  // :15-19
+                const unsigned pos = base + (unsigned)__popcll(m & lanemask_lt());
+                s_q2pix[pos] = pix;
+                s_pw[pos] = row_apply(F.Twk, 0, pcx, pcy, pcz);          // :144
+                s_pw[kTile + pos] = row_apply(F.Twk, 1, pcx, pcy, pcz);
+                s_pw[2 * kTile + pos] = row_apply(F.Twk, 2, pcx, pcy, pcz);
+            }
         }
-        // phase 2: wave w re-observes the pixel in neighbours w, w+NW, ...  (:187-216)
+    }
+    __syncthreads();
+    SFM_STAMP(2);
+    const uint32_t n2 = s_cnt[2];
+    if (n2 == 0) return;  // uniform
+    // one reservation per workgroup: an entry per surviving pixel.  Issued now, consumed after
+    // the first chunk's neighbour work, so its round trip hides under the arithmetic.
+    unsigned long long base_r = 0;
+    if (w == 0 && lane == 0) base_r = atomicAdd(&a.list.cursor[shard * 8], (unsigned long long)n2);
+
+    for (uint32_t c0 = 0; c0 < n2; c0 += kWave) {
+        const bool act = c0 + lane < n2;
+        const unsigned p3 = (blockIdx.x + (c0 >> 6)) % NW;  // wave that finishes this chunk
+        double pwx = 0, pwy = 0, pwz = 0;
+        uint32_t pix = 0, col = 0;
+        if (act) {
+            pwx = s_pw[c0 + lane];
+            pwy = s_pw[kTile + c0 + lane];
+            pwz = s_pw[2 * kTile + c0 + lane];
+            if (w == p3) {                                               // :170, features.cpp:76-80
+                pix = s_q2pix[c0 + lane];
+                const uint8_t *cp = F.bgr + 3ull * pix;
+                col = (uint32_t)cp[0] | ((uint32_t)cp[1] << 8) | ((uint32_t)cp[2] << 16);
+            }
+        }
+        // wave w re-observes the chunk in neighbours w, w+NW, ...  (:187-216)
         unsigned n_gather = 0;
         for (uint32_t k = w; k < K; k += NW) {
-            const uint32_t nb = nbr_idx[F.nbr_begin + k];
-            const FrameDev &L = frames[nb];
+            const FrameDev &L = nbp[k];
             bool kept = false, close = false, vis = false;
-            if (ok) {
+            if (act) {
                 // KeyFrame::point_in_frame, keyframe.cpp:275-294 / pinhole.cpp:32-45
                 const double cx_ = row_apply(L.Tkw, 0, pwx, pwy, pwz);
                 const double cy_ = row_apply(L.Tkw, 1, pwx, pwy, pwz);
@@ -311,10 +376,16 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
                 s_close[k] = mc_;
             }
         }
-        if (lane == 0 && n_gather) atomicAdd(&s_cnt[0], n_gather);
+        if (lane == 0) {
+            if (n_gather) atomicAdd(&s_cnt[0], n_gather);
+            if (w == 0 && c0 == 0) *s_base = base_r;
+        }
+        if (c0 == 0) SFM_STAMP(3);
         __syncthreads();
-        // phase 3 (wave 0): decision, mask scatter, weighted fusion, record
-        if (w == 0) {
+        if (c0 == 0) SFM_STAMP(4);
+        // decision, mask scatter, weighted fusion, record: one wave per chunk
+        if (w == p3) {
+            bool ok = act;
             unsigned n_obs = 0, n_close = 0;
             double wx = 0, wy = 0, wz = 0, total = 0;
             for (uint32_t k = 0; k < K; k++) {                           // neighbour order, :160-163
@@ -337,9 +408,8 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
                 for (uint32_t k = 0; k < K; k++) {                           // :152-154
                     if ((s_kept[k] >> lane) & 1ull) {
                         c_hit++;
-                        const uint32_t nb = nbr_idx[F.nbr_begin + k];
                         // masks of already-processed keyframes are never read again
-                        if (nb > a.f) frames[nb].mask[s_hit[k * 64 + lane]] = 255;
+                        if (nbp[k].order > a.f) nbp[k].mask[s_hit[k * 64 + lane]] = 255;
                     }
                 }
                 fx = wx / total; fy = wy / total; fz = wz / total;           // :164
@@ -371,25 +441,20 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
                 }
             }
             c_hit = wave_sum(c_hit);
-            if (lane == 0) s_cnt[1] += c_hit;
+            if (lane == 0 && c_hit) atomicAdd(&s_cnt[1], c_hit);
+            if (c0 == 0) SFM_STAMP(5);
         }
-        if (c0 + kWave < qn) __syncthreads();  // s_obs/s_kept are reused by the next chunk
+        __syncthreads();  // s_obs/s_kept are reused by the next chunk; s_cnt complete at the end
     }
-
-    if (w == 0) {
-        unsigned last = 0;
-        if (lane == 0) {
-            StatShard *st = &a.stat[blockIdx.x % kStatShards];
-            if (s_cnt[0]) atomicAdd(&st->n_gather, (unsigned long long)s_cnt[0]);
-            if (s_cnt[1]) atomicAdd(&st->n_hit, (unsigned long long)s_cnt[1]);
-            // this workgroup's cursor reservation has returned (s_base was read above)
-            last = atomicAdd(&a.frame_done[a.f], 1u) == gridDim.x - 1;
-        }
-        last = __shfl(last, 0);
-        if (last && lane < kListShards)
-            a.list.frame_end[(size_t)a.f * kListShards + lane] =
-                atomicAdd(&a.list.cursor[lane * 8], 0ull);
+    if (w == 0 && lane == 0) {
+        StatShard *st = &a.stat[blockIdx.x % kStatShards];
+        if (s_cnt[0]) atomicAdd(&st->n_gather, (unsigned long long)s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&st->n_hit, (unsigned long long)s_cnt[1]);
     }
+    SFM_STAMP(6);
+#ifdef SFM_STAMPS
+    if (a.stamps && w == 0 && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] = n2;
+#endif
 }
 
 // ---- voxel table: first-wins filter for a group of keyframes ------------------------------
@@ -419,8 +484,9 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
     if (threadIdx.x == 0) { s_claims = 0; s_maxprobe = 0; s_err = 0; }
     __syncthreads();
     const uint32_t shard = blockIdx.y;
-    const unsigned long long begin = a.f0 ? a.list.frame_end[(size_t)(a.f0 - 1) * kListShards + shard] : 0ull;
-    unsigned long long end = a.list.frame_end[(size_t)(a.f1 - 1) * kListShards + shard];
+    const unsigned long long begin =
+        a.group ? a.list.group_end[(size_t)(a.group - 1) * kListShards * 8 + shard * 8] : 0ull;
+    unsigned long long end = a.list.group_end[(size_t)a.group * kListShards * 8 + shard * 8];
     if (end > a.list.shard_cap) end = a.list.shard_cap;
     const unsigned long long base = (unsigned long long)shard * a.list.shard_cap;
     const unsigned long long want_hi = (unsigned long long)a.group + 1ull;
@@ -447,7 +513,12 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
         }
         if (!found) { s_err = kErrTableFull; continue; }
         if (probes > maxprobe) maxprobe = probes;
-        if (a.table[h].tag > tag) atomicMin(&a.table[h].tag, tag);
+        // An entry that is not the smallest tag of its voxel at this moment can never win:
+        // drop it from the list so finalize_kernel does not probe for it again.
+        const unsigned long long seen = a.table[h].tag;
+        unsigned long long prev_tag = seen;
+        if (seen > tag) prev_tag = atomicMin(&a.table[h].tag, tag);
+        if (prev_tag < tag) a.list.tag[base + i] = kEmpty;
         const unsigned long long bit = 1ull << fr;
         unsigned long long old = a.mark[h];
         for (;;) {
