@@ -60,6 +60,7 @@ struct sfm_fusion_ctx {
     std::vector<HostFrame> frames;
     bool layout_dirty = true;
 
+    DevBuf<double> d_tables;         // x/y/covariance lookup tables
     DevBuf<FrameDev> d_nbrpack;      // per keyframe: a FrameDev copy of each filtered neighbour
     std::vector<FrameDev> h_frames;  // device-side description of every keyframe (host copy)
     DevBuf<uint8_t> d_masks;
@@ -191,6 +192,47 @@ int build_layout(sfm_fusion_ctx *c)
     std::vector<FrameDev> &fd = c->h_frames;
     fd.assign(n, FrameDev());
     std::vector<uint32_t> nbr;
+    // lookup tables, one per distinct (f, c, extent) / focal length
+    struct Axis { double f, c; int n; size_t off; };
+    std::vector<Axis> axes;
+    std::vector<std::pair<double, size_t>> covs;
+    size_t tab_doubles = 0;
+    auto axis_of = [&](double f, double cc, int len) {
+        for (auto &a : axes)
+            if (std::memcmp(&a.f, &f, 8) == 0 && std::memcmp(&a.c, &cc, 8) == 0 && a.n == len) return a.off;
+        axes.push_back({f, cc, len, tab_doubles});
+        tab_doubles += ((size_t)std::max(len, 1) + 1) / 2 * 2;
+        return axes.back().off;
+    };
+    auto cov_of = [&](double f) {
+        for (auto &e : covs)
+            if (std::memcmp(&e.first, &f, 8) == 0) return e.second;
+        covs.push_back({f, tab_doubles});
+        tab_doubles += 4 * 65536;
+        return covs.back().second;
+    };
+    std::vector<size_t> xo(n), yo(n), co(n);
+    for (size_t i = 0; i < n; i++) {
+        const HostFrame &f = c->frames[i];
+        co[i] = cov_of(f.K[0]);
+        xo[i] = axis_of(f.K[0], f.K[2], f.W);
+        yo[i] = axis_of(f.K[1], f.K[3], f.H);
+    }
+    if ((rc = ensure(c, c->d_tables, tab_doubles))) return rc;
+    {
+        DevParams P;
+        P.base_line = c->prm.base_line; P.T_cov = c->prm.T_cov; P.voxel_size = c->prm.voxel_size;
+        P.tau_dist2 = 0; P.S0 = c->prm.S[0]; P.S1 = c->prm.S[1]; P.S2 = c->prm.S[2];
+        P.depth_div = c->prm.depth_div; P.close_frac = c->prm.close_frac;
+        for (auto &e : covs)
+            hipLaunchKernelGGL(build_cov_table, dim3(256), dim3(256), 0, c->stream, c->d_tables.p + e.second, e.first, P);
+        for (auto &a : axes)
+            if (a.n > 0)
+                hipLaunchKernelGGL(build_axis_table, dim3((a.n + 255) / 256), dim3(256), 0, c->stream,
+                                   c->d_tables.p + a.off, a.n, a.c, a.f);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     for (size_t i = 0; i < n; i++) {
         HostFrame &f = c->frames[i];
         FrameDev &d = fd[i];
@@ -200,6 +242,9 @@ int build_layout(sfm_fusion_ctx *c)
         d.depth = f.d_depth;
         d.bgr = f.d_bgr;
         d.mask = c->d_masks.p + moff[i];
+        d.xtab = c->d_tables.p + xo[i];
+        d.ytab = c->d_tables.p + yo[i];
+        d.ctab = c->d_tables.p + co[i];
         d.W = f.W;
         d.H = f.H;
         d.nbr_begin = (uint32_t)nbr.size();
@@ -301,9 +346,11 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
         const uint64_t px = (uint64_t)f.W * f.H;
         // a keyframe without pixels still runs one (empty) workgroup so that its list
         // boundary frame_end[] is published
-        const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, (px + kTile - 1) / kTile);
         const uint32_t nw = std::min<uint32_t>(std::max<uint32_t>(f.n_filtered, 1), c->max_waves);
-        const size_t lds = fuse_lds_bytes(f.n_filtered);
+        // 64-pixel sub-tiles, nw of them (one per wave, strided by the grid) per workgroup
+        const uint64_t nsub = (px + kWave - 1) / kWave;
+        const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, (nsub + nw - 1) / nw);
+        const size_t lds = fuse_lds_bytes(f.n_filtered, nw);
         a.f = (uint32_t)i;
         a.F = c->h_frames[i];
 #ifdef SFM_STAMPS
@@ -458,7 +505,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
         if (f.d_depth) (void)hipFree(f.d_depth);
         if (f.d_bgr) (void)hipFree(f.d_bgr);
     }
-    release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
+    release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
     release(c->d_mark); release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
     release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_group_end);

@@ -45,6 +45,10 @@ struct FrameDev {
     const uint16_t *depth;  // W*H, packed rows
     const uint8_t *bgr;     // W*H*3
     uint8_t *mask;          // W*H visibility mask (dense_reconstruction.hpp:35-39)
+    // exact lookup tables shared by keyframes with the same intrinsics (build_*_table below)
+    const double *xtab;     // [W]  (u - cx) / fx                        pinhole.cpp:12
+    const double *ytab;     // [H]  (v - cy) / fy                        pinhole.cpp:13
+    const double *ctab;     // [65536][4] depth-only terms of trace(J S J^T), see cov_trace_tab
     int32_t W, H;
     uint32_t nbr_begin, nbr_count;  // filtered neighbours in nbr_idx[]
     uint32_t order, pad;
@@ -130,6 +134,44 @@ __device__ __forceinline__ double cov_trace(const DevParams &P, int u, int v, do
     return P00 + (P11 + P22);
 }
 
+// Same value as cov_trace(), bit for bit, with the four divisions that depend on the depth
+// alone taken from the per-focal-length table e = ctab + 4*depth:
+//   e[0] = (J00*S0)*J00, e[1] = (J00*S1)*J00, e[2] = disparity^2, e[3] = (J22*S2)*J22.
+__device__ __forceinline__ double cov_trace_tab(const DevParams &P, int u, int v, const double *e)
+{
+    const double2 e01 = *reinterpret_cast<const double2 *>(e);
+    const double2 e23 = *reinterpret_cast<const double2 *>(e + 2);
+    const double dd = e23.x;
+    const double J02 = ((double)(-u) * P.base_line) / dd;
+    const double J12 = ((double)(-v) * P.base_line) / dd;
+    const double P00 = e01.x + (J02 * P.S2) * J02;
+    const double P11 = e01.y + (J12 * P.S2) * J12;
+    return P00 + (P11 + e23.y);
+}
+
+// One entry per raw depth value for focal length f; the operations and their order are those
+// of cov_trace().
+__global__ __launch_bounds__(256) void build_cov_table(double *tab, double f, DevParams P)
+{
+    const unsigned d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= 65536u) return;
+    const double disp = (f * P.base_line) / ((double)d / P.depth_div);
+    const double dd = disp * disp;
+    const double J00 = P.base_line / disp;
+    const double J22 = ((-f) * P.base_line) / dd;
+    tab[4 * d + 0] = (J00 * P.S0) * J00;
+    tab[4 * d + 1] = (J00 * P.S1) * J00;
+    tab[4 * d + 2] = dd;
+    tab[4 * d + 3] = (J22 * P.S2) * J22;
+}
+
+// tab[i] = (i - c) / f   (pinhole.cpp:12-13)
+__global__ __launch_bounds__(256) void build_axis_table(double *tab, int n, double c, double f)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) tab[i] = ((double)i - c) / f;
+}
+
 // row r of T*[p;1]: Homogeneous product = leftCols<3>()*p (inner index ascending) + col(3).
 __device__ __forceinline__ double row_apply(const double *T, int r, double x, double y, double z)
 {
@@ -184,8 +226,10 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 
 // ---- the per-keyframe kernel ------------------------------------------------------------
 //
-// Workgroup = one 256-pixel tile, NW waves.  Stages:
-//   A  every wave: coalesced tile load + ballot/popcount compaction of live pixels into s_q
+// Workgroup = NW waves, 64*NW pixels.  Stages:
+//   A  wave w scans the 64-pixel sub-tile blockIdx.x + w*gridDim.x (coalesced rows; a
+//      workgroup's pixels are spread over the image so dense and sparse regions average out)
+//      and ballot/popcount-compacts its live pixels into the shared queue s_q
 //   B  live chunks dealt round-robin to the waves: covariance gate + back-projection; the
 //      survivors are re-compacted into s_q2 (pixel, world point)
 //   C  per 64-survivor chunk: wave w re-observes the chunk in neighbours w, w+NW, ...;
@@ -196,11 +240,12 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 //   s_obs  [K][4][64] double   per neighbour, per lane: q*(1/w) (x,y,z) and 1/w
 //   s_hit  [K][64]    u32      re-observed pixel in the neighbour
 //   s_kept [K], s_close[K] u64 ballots: observation kept (:204) / within T_dist (:224)
-//   s_pw   [3][256]   double   world point of each survivor
-//   s_base u64, s_cnt[4] u32, s_qpix[256] u32, s_q2pix[256] u32, s_qd[256] u16
-__host__ __device__ inline size_t fuse_lds_bytes(uint32_t K)
+//   s_pw   [3][Q]     double   world point of each survivor          (Q = 64*NW pixels)
+//   s_base u64, s_cnt[4] u32, s_qpix[Q] u32, s_q2pix[Q] u32, s_qd[Q] u16
+__host__ __device__ inline size_t fuse_lds_bytes(uint32_t K, uint32_t NW)
 {
-    return (size_t)K * (4 * 64 * 8 + 64 * 4 + 16) + 3 * kTile * 8 + 8 + 16 + kTile * 4 + kTile * 4 + kTile * 2;
+    const size_t Q = (size_t)NW * kWave;
+    return (size_t)K * (4 * 64 * 8 + 64 * 4 + 16) + 3 * Q * 8 + 8 + 16 + Q * 4 + Q * 4 + Q * 2;
 }
 
 // process_pixel + geometric_check (dense_reconstruction.cpp:126-234).
@@ -221,12 +266,13 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
     uint32_t *s_hit = reinterpret_cast<uint32_t *>(s_obs + (size_t)K * 256);
     unsigned long long *s_kept = reinterpret_cast<unsigned long long *>(s_hit + (size_t)K * 64);
     unsigned long long *s_close = s_kept + K;
+    const uint32_t Q = NW * kWave;
     double *s_pw = reinterpret_cast<double *>(s_close + K);
-    unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_pw + 3 * kTile);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_base + 1);  // [0] gathers [1] hits [2] survivors
+    unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_pw + 3 * Q);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_base + 1);  // gathers, hits, survivors, live
     uint32_t *s_qpix = s_cnt + 4;
-    uint32_t *s_q2pix = s_qpix + kTile;
-    uint16_t *s_qd = reinterpret_cast<uint16_t *>(s_q2pix + kTile);
+    uint32_t *s_q2pix = s_qpix + Q;
+    uint16_t *s_qd = reinterpret_cast<uint16_t *>(s_q2pix + Q);
 
     const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
     const uint32_t shard = blockIdx.x % kListShards;
@@ -235,55 +281,45 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
     return;
 #endif
 
-    // -- stage A: tile load + ballot/popcount compaction of live pixels (:100-101).  Every wave
-    //    builds the same queue (identical values to identical LDS addresses).
-    uint32_t qn = 0;
+    // -- stage A: sub-tile scan + ballot/popcount compaction of live pixels (:100-101)
+    if (w == 0 && lane < 4) s_cnt[lane] = 0;
+    __syncthreads();
     {
-        const uint32_t i0 = blockIdx.x * kTile + lane * kPxPerLane;
-        uint16_t d[kPxPerLane];
-        uint8_t mk[kPxPerLane];
-        if (i0 + kPxPerLane <= npx) {
-            const ushort4 dv = *reinterpret_cast<const ushort4 *>(F.depth + i0);
-            const uchar4 mv = *reinterpret_cast<const uchar4 *>(F.mask + i0);
-            d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
-            mk[0] = mv.x; mk[1] = mv.y; mk[2] = mv.z; mk[3] = mv.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < kPxPerLane; j++) {
-                const bool in = i0 + j < npx;
-                d[j] = in ? F.depth[i0 + j] : (uint16_t)0;
-                mk[j] = in ? F.mask[i0 + j] : (uint8_t)255;
-            }
+        const uint32_t t = blockIdx.x + w * gridDim.x;
+        const uint32_t i = t * kWave + lane;
+        uint16_t d = 0;
+        bool live = false;
+        if (i < npx && K > 0) {                                          // K==0: :180 rejects all
+            d = F.depth[i];
+            live = (F.mask[i] == 0) && (d > 0);
         }
-#pragma unroll
-        for (int j = 0; j < kPxPerLane; j++) {
-            const bool live = (mk[j] == 0) && (d[j] > 0) && (K > 0);  // K==0: :180 rejects all
-            const unsigned long long m = __ballot(live);
+        const unsigned long long m = __ballot(live);
+        if (m != 0) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned base = 0;
+            if ((int)lane == leader) base = atomicAdd(&s_cnt[3], (unsigned)__popcll(m));
+            base = __shfl(base, leader);
             if (live) {
-                const unsigned pos = qn + (unsigned)__popcll(m & lanemask_lt());
-                s_qpix[pos] = i0 + j;
-                s_qd[pos] = d[j];
+                const unsigned pos = base + (unsigned)__popcll(m & lanemask_lt());
+                s_qpix[pos] = i;
+                s_qd[pos] = d;
             }
-            qn += (unsigned)__popcll(m);
         }
-    }
-    SFM_STAMP(1);
-    if (qn == 0) return;  // uniform over the workgroup
-    if (w == 0 && lane == 0) {
-        s_cnt[0] = 0;
-        s_cnt[1] = 0;
-        s_cnt[2] = 0;
     }
     __syncthreads();
+    SFM_STAMP(1);
+    const uint32_t qn = s_cnt[3];
+    if (qn == 0) return;  // uniform over the workgroup
 
     // -- stage B: covariance gate + back-projection, chunks dealt to the waves
     for (uint32_t c0 = w * kWave; c0 < qn; c0 += NW * kWave) {
         const bool act = c0 + lane < qn;
         const uint32_t pix = act ? s_qpix[c0 + lane] : 0u;
-        const double dsrc = act ? (double)s_qd[c0 + lane] : 1.0;
+        const uint32_t draw = act ? (uint32_t)s_qd[c0 + lane] : 1u;
+        const double dsrc = (double)draw;
         const int u = (int)(pix % (uint32_t)F.W);
         const int v = (int)(pix / (uint32_t)F.W);
-        const double tr = cov_trace(P, u, v, dsrc, F.K[0]);              // :136
+        const double tr = cov_trace_tab(P, u, v, F.ctab + 4 * (size_t)draw);  // :136
         const bool pass = act && !(tr > P.T_cov);                        // :138
         const unsigned long long m = __ballot(pass);
         if (m != 0) {
@@ -292,14 +328,14 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
             if ((int)lane == leader) base = atomicAdd(&s_cnt[2], (unsigned)__popcll(m));
             base = __shfl(base, leader);
             if (pass) {
-                const double xn = ((double)u - F.K[2]) / F.K[0];         // pinhole.cpp:12
-                const double yn = ((double)v - F.K[3]) / F.K[1];
+                const double xn = F.xtab[u];                             // pinhole.cpp:12
+                const double yn = F.ytab[v];
                 const double pcx = xn * dsrc, pcy = yn * dsrc, pcz = dsrc;  // :15-19
                 const unsigned pos = base + (unsigned)__popcll(m & lanemask_lt());
                 s_q2pix[pos] = pix;
                 s_pw[pos] = row_apply(F.Twk, 0, pcx, pcy, pcz);          // :144
-                s_pw[kTile + pos] = row_apply(F.Twk, 1, pcx, pcy, pcz);
-                s_pw[2 * kTile + pos] = row_apply(F.Twk, 2, pcx, pcy, pcz);
+                s_pw[Q + pos] = row_apply(F.Twk, 1, pcx, pcy, pcz);
+                s_pw[2 * Q + pos] = row_apply(F.Twk, 2, pcx, pcy, pcz);
             }
         }
     }
@@ -319,8 +355,8 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
         uint32_t pix = 0, col = 0;
         if (act) {
             pwx = s_pw[c0 + lane];
-            pwy = s_pw[kTile + c0 + lane];
-            pwz = s_pw[2 * kTile + c0 + lane];
+            pwy = s_pw[Q + c0 + lane];
+            pwz = s_pw[2 * Q + c0 + lane];
             if (w == p3) {                                               // :170, features.cpp:76-80
                 pix = s_q2pix[c0 + lane];
                 const uint8_t *cp = F.bgr + 3ull * pix;
@@ -345,14 +381,15 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
                     const int ix = (int)floor(px);
                     const int iy = (int)floor(py);
                     const uint32_t npix = (uint32_t)iy * (uint32_t)L.W + (uint32_t)ix;
-                    const double d = (double)L.depth[npix];              // :193 (no d>0 test)
-                    const double x = ((double)ix - L.K[2]) / L.K[0];
-                    const double y = ((double)iy - L.K[3]) / L.K[1];
+                    const uint32_t draw = L.depth[npix];                 // :193 (no d>0 test)
+                    const double d = (double)draw;
+                    const double x = L.xtab[ix];
+                    const double y = L.ytab[iy];
                     const double qcx = x * d, qcy = y * d, qcz = d;
                     const double qx = row_apply(L.Twk, 0, qcx, qcy, qcz);
                     const double qy = row_apply(L.Twk, 1, qcx, qcy, qcz);
                     const double qz = row_apply(L.Twk, 2, qcx, qcy, qcz);
-                    const double wgt = cov_trace(P, ix, iy, d, L.K[0]);  // :202
+                    const double wgt = cov_trace_tab(P, ix, iy, L.ctab + 4 * (size_t)draw);  // :202
                     if (wgt < P.T_cov) {                                 // :204
                         kept = true;
                         const double dx = qx - pwx, dy = qy - pwy, dz = qz - pwz;
