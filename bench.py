@@ -93,6 +93,8 @@ def main():
     merger = None
     if world > 1:
         from sfm_amd import dist_fusion
+        # this rank's keyframes sit at [rank*n_kf, (rank+1)*n_kf) of the global processing order
+        ctx.set_global_order(np.arange(n_kf, dtype=np.uint32) + rank * n_kf)
         merger = dist_fusion.VoxelExchange(ctx, rank, world, dev)
 
     def step():

@@ -131,6 +131,25 @@ int sfm_fusion_set_profiling(sfm_fusion_ctx *ctx, int enable);
 /* per-frame "Points before/after voxel filter" (:118-120); arrays of n_frames. */
 int sfm_fusion_get_frame_counts(sfm_fusion_ctx *ctx, uint64_t *before, uint64_t *after);
 
+/* ---- multi-GPU: one ctx per GPU, each fusing whole covisibility components ----------------
+ * No reference counterpart (the reference is single-process).  Keyframes are sharded by
+ * covisibility component (the visibility-mask chain never crosses components); the global
+ * voxel filter (src/dense_reconstruction.cpp:57) becomes: bucket every GPU's winners by
+ * owner = hash(voxel key) mod n_parts, all-to-all the buckets (RCCL, done by the caller),
+ * min-reduce per owner.  The union of the owners' clouds is the reference's cloud. */
+#define SFM_RECORD_BYTES 48 /* {u64 key, u64 tag, f64 x,y,z, u32 bgr, u32 pad} */
+
+/* Global processing order of each of this ctx's keyframes (strictly increasing, one entry per
+ * keyframe).  Exported records and sfm_fusion_read_points tags then carry global orders. */
+int sfm_fusion_set_global_order(sfm_fusion_ctx *ctx, const uint32_t *order, uint32_t n);
+/* After sfm_fusion_run: how many local winners each of n_parts owners gets. */
+int sfm_fusion_partition_counts(sfm_fusion_ctx *ctx, uint32_t n_parts, uint64_t *counts);
+/* Writes the local winners as records, grouped by owner in owner order, into device memory. */
+int sfm_fusion_export_records(sfm_fusion_ctx *ctx, void *dst_dev, uint64_t dst_bytes);
+/* Owner side: first-wins reduce over n received records (device memory); the result replaces
+ * this ctx's cloud (sfm_fusion_num_points / sfm_fusion_read_points). */
+int sfm_fusion_merge(sfm_fusion_ctx *ctx, const void *records_dev, uint64_t n);
+
 const char *sfm_fusion_last_error(sfm_fusion_ctx *ctx);
 const char *sfm_fusion_version(void);
 

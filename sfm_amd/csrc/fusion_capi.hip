@@ -82,6 +82,11 @@ struct sfm_fusion_ctx {
     bool profile = false;         // per-launch start/stop events on the frame kernels
     std::vector<hipEvent_t> kev;  // 2 per keyframe when profiling
 
+    std::vector<uint32_t> global_order; // multi-GPU: global processing order of each keyframe
+    DevBuf<uint32_t> d_gorder;
+    bool merged = false;                // cloud tags already carry global orders
+    DevBuf<unsigned long long> d_part; // [2 * n_parts] bucket counts, then scatter cursors
+    std::vector<uint64_t> part_counts; // last sfm_fusion_partition_counts result
     uint64_t total_px = 0;
     uint64_t n_out = 0;
     bool have_result = false;
@@ -505,7 +510,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
         if (f.d_depth) (void)hipFree(f.d_depth);
         if (f.d_bgr) (void)hipFree(f.d_bgr);
     }
-    release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
+    release(c->d_part); release(c->d_gorder); release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
     release(c->d_mark); release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
     release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_group_end);
@@ -626,6 +631,7 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
         }
     }
     c->n_out = c->h_small->ctr.out_count;
+    c->merged = false;
     sfm_fusion_stats &st = c->stats;
     std::memset(&st, 0, sizeof st);
     st.n_frames = n;
@@ -669,6 +675,107 @@ int sfm_fusion_set_profiling(sfm_fusion_ctx *c, int enable)
 {
     if (!c) return SFM_E_INVALID;
     c->profile = enable != 0;
+    return SFM_OK;
+}
+
+int sfm_fusion_set_global_order(sfm_fusion_ctx *c, const uint32_t *order, uint32_t n)
+{
+    if (!c) return SFM_E_INVALID;
+    if (n != c->frames.size() || (n && !order))
+        return fail(c, SFM_E_INVALID, "global order must cover every keyframe");
+    for (uint32_t i = 1; i < n; i++)
+        if (order[i] <= order[i - 1]) return fail(c, SFM_E_INVALID, "global order must be strictly increasing");
+    c->global_order.assign(order, order + n);
+    return SFM_OK;
+}
+
+int sfm_fusion_partition_counts(sfm_fusion_ctx *c, uint32_t n_parts, uint64_t *counts)
+{
+    if (!c || !counts || n_parts == 0 || n_parts > 1024) return fail(c, SFM_E_INVALID, "bad partition argument");
+    if (!c->have_result) return fail(c, SFM_E_INVALID, "no result: call sfm_fusion_run first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->d_part, 2ull * n_parts))) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_part.p, 0, 2ull * n_parts * sizeof(unsigned long long), s));
+    if (c->n_out) {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((c->n_out + 255) / 256, 1024);
+        hipLaunchKernelGGL(partition_count_kernel, dim3(blocks), dim3(256), 0, s, c->d_out_key.p,
+                           (unsigned long long)c->n_out, n_parts, c->d_part.p);
+        HIP_TRY(c, hipGetLastError());
+    }
+    c->part_counts.assign(n_parts, 0);
+    HIP_TRY(c, hipMemcpyAsync(c->part_counts.data(), c->d_part.p, n_parts * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    std::copy(c->part_counts.begin(), c->part_counts.end(), counts);
+    return SFM_OK;
+}
+
+int sfm_fusion_export_records(sfm_fusion_ctx *c, void *dst_dev, uint64_t dst_bytes)
+{
+    if (!c) return SFM_E_INVALID;
+    if (!c->have_result || c->part_counts.empty())
+        return fail(c, SFM_E_INVALID, "call sfm_fusion_run and sfm_fusion_partition_counts first");
+    if (dst_bytes < c->n_out * sizeof(Record) || (c->n_out && !dst_dev))
+        return fail(c, SFM_E_INVALID, "export buffer too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t n_parts = (uint32_t)c->part_counts.size();
+    std::vector<uint64_t> start(n_parts, 0);
+    for (uint32_t p = 1; p < n_parts; p++) start[p] = start[p - 1] + c->part_counts[p - 1];
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->d_part.p + n_parts, start.data(), n_parts * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    std::vector<uint32_t> go = c->global_order;
+    if (go.size() != c->frames.size()) {
+        go.resize(c->frames.size());
+        std::iota(go.begin(), go.end(), 0u);
+    }
+    int rc;
+    if ((rc = ensure(c, c->d_gorder, go.size()))) return rc;
+    if (!go.empty())
+        HIP_TRY(c, hipMemcpyAsync(c->d_gorder.p, go.data(), go.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (c->n_out) {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((c->n_out + 255) / 256, 2048);
+        hipLaunchKernelGGL(partition_scatter_kernel, dim3(blocks), dim3(256), 0, s, c->d_out_key.p, c->d_out_tag.p,
+                           c->d_out_xyz.p, c->d_out_bgr.p, (unsigned long long)c->n_out, n_parts,
+                           (const uint32_t *)c->d_gorder.p, c->d_part.p + n_parts, (Record *)dst_dev);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));  // start[] and go[] live on this stack frame
+    return SFM_OK;
+}
+
+int sfm_fusion_merge(sfm_fusion_ctx *c, const void *records_dev, uint64_t n)
+{
+    if (!c || (n && !records_dev)) return SFM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    const uint64_t table_cap = pow2_at_least(std::max<uint64_t>(2 * n, 1 << 16));
+    if ((rc = ensure(c, c->d_table, table_cap))) return rc;
+    if ((rc = ensure(c, c->d_out_key, n))) return rc;
+    if ((rc = ensure(c, c->d_out_tag, n))) return rc;
+    if ((rc = ensure(c, c->d_out_xyz, 3 * n))) return rc;
+    if ((rc = ensure(c, c->d_out_bgr, n))) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0xFF, table_cap * sizeof(Slot), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_small, 0, sizeof(Counters), s));
+    if (n) {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(merge_insert_kernel, dim3(blocks), dim3(256), 0, s, (const Record *)records_dev,
+                           (unsigned long long)n, c->d_table.p, table_cap - 1, dev_ctr(c));
+        hipLaunchKernelGGL(merge_finalize_kernel, dim3(blocks), dim3(256), 0, s, (const Record *)records_dev,
+                           (unsigned long long)n, (const Slot *)c->d_table.p, table_cap - 1, dev_ctr(c),
+                           c->d_out_xyz.p, c->d_out_bgr.p, c->d_out_key.p, c->d_out_tag.p);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipMemcpyAsync(&c->h_small->ctr, c->d_small, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->h_small->ctr.err) return fail(c, SFM_E_TABLE_FULL, "merge table overflow");
+    c->n_out = c->h_small->ctr.out_count;
+    c->stats.n_vox = c->n_out;
+    c->stats.global_after = c->n_out;
+    c->part_counts.clear();
+    c->merged = true;
+    c->have_result = true;
     return SFM_OK;
 }
 
@@ -719,7 +826,12 @@ int sfm_fusion_read_points(sfm_fusion_ctx *c, double *xyz, int32_t *bgr, uint64_
         if (xyz) { xyz[3 * o] = hx[3 * i]; xyz[3 * o + 1] = hx[3 * i + 1]; xyz[3 * o + 2] = hx[3 * i + 2]; }
         if (bgr) { bgr[3 * o] = hc[i] & 255; bgr[3 * o + 1] = (hc[i] >> 8) & 255; bgr[3 * o + 2] = (hc[i] >> 16) & 255; }
         if (key) { key[3 * o] = k0[i]; key[3 * o + 1] = k1[i]; key[3 * o + 2] = k2[i]; }
-        if (tag) tag[o] = ht[i];
+        if (tag) {
+            uint64_t t = ht[i];
+            if (!c->merged && c->global_order.size() == c->frames.size() && (t >> 32) < c->global_order.size())
+                t = ((uint64_t)c->global_order[t >> 32] << 32) | (t & 0xFFFFFFFFull);
+            tag[o] = t;
+        }
     }
     return SFM_OK;
 }

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
                     if ((s_kept[k] >> lane) & 1ull) {
                         c_hit++;
                         // masks of already-processed keyframes are never read again
-                        if (nbp[k].order > a.f) nbp[k].mask[s_hit[k * 64 + lane]] = 255;
+                        if (nbp[k].order > F.order) nbp[k].mask[s_hit[k * 64 + lane]] = 255;
                     }
                 }
                 fx = wx / total; fy = wy / total; fz = wz / total;           // :164
@@ -504,7 +504,7 @@ struct TableArgs {
     Counters *ctr;
     unsigned long long *frame_before;  // [n_frames] "Points before voxel filter" (:118)
     unsigned long long *frame_after;   // [n_frames] "Points after voxel filter"  (:120)
-    uint32_t f0, f1;                   // keyframes [f0, f1), f1 - f0 <= kGroup
+    uint32_t f0, f1;                   // keyframes [f0, f1), f1 - f0 <= kGroup (local indices)
     uint32_t group;
 };
 
@@ -633,6 +633,132 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
                 a.out_bgr[o] = a.list.bgr[base + i];
                 a.out_key[o] = key;
                 a.out_tag[o] = tag;
+            }
+        }
+    }
+}
+
+// ---- multi-GPU: exchange by voxel-key hash partition, per-owner reduce --------------------
+//
+// After the local run every GPU holds the winners of its own keyframes.  Winners are bucketed
+// by owner = part_of(key); the buckets travel by RCCL all-to-all (host side, sfm_amd/
+// dist_fusion.py); each owner min-reduces what it receives in a fresh table and compacts.
+
+struct Record {  // 48 bytes on the wire
+    unsigned long long key;  // packed voxel key
+    unsigned long long tag;  // (global keyframe order << 32) | pixel
+    double x, y, z;
+    uint32_t bgr, pad;
+};
+
+__device__ __forceinline__ uint32_t part_of(unsigned long long key, uint32_t n_parts)
+{
+    return (uint32_t)((mix64(key ^ 0x9E3779B97F4A7C15ull) >> 17) % n_parts);
+}
+
+// counts[p] += number of output points owned by part p (n_parts <= 1024)
+__global__ __launch_bounds__(256) void partition_count_kernel(const unsigned long long *out_key,
+                                                              unsigned long long n, uint32_t n_parts,
+                                                              unsigned long long *counts)
+{
+    __shared__ unsigned int s_c[1024];
+    for (uint32_t i = threadIdx.x; i < n_parts; i += blockDim.x) s_c[i] = 0;
+    __syncthreads();
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        atomicAdd(&s_c[part_of(out_key[i], n_parts)], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_parts; i += blockDim.x)
+        if (s_c[i]) atomicAdd(&counts[i], (unsigned long long)s_c[i]);
+}
+
+// cursors[p] starts at the bucket's first record index
+__global__ __launch_bounds__(256) void partition_scatter_kernel(const unsigned long long *out_key,
+                                                                const unsigned long long *out_tag,
+                                                                const double *out_xyz, const uint32_t *out_bgr,
+                                                                unsigned long long n, uint32_t n_parts,
+                                                                const uint32_t *global_order,
+                                                                unsigned long long *cursors, Record *dst)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long key = out_key[i];
+        const unsigned long long o = atomicAdd(&cursors[part_of(key, n_parts)], 1ull);
+        Record r;
+        r.key = key;
+        const unsigned long long t = out_tag[i];  // local keyframe index -> global order
+        r.tag = ((unsigned long long)global_order[t >> 32] << 32) | (t & 0xFFFFFFFFull);
+        r.x = out_xyz[3 * i + 0];
+        r.y = out_xyz[3 * i + 1];
+        r.z = out_xyz[3 * i + 2];
+        r.bgr = out_bgr[i];
+        r.pad = 0;
+        dst[o] = r;
+    }
+}
+
+// owner side, pass 1: first-wins over everything received (min tag per key)
+__global__ __launch_bounds__(256) void merge_insert_kernel(const Record *rec, unsigned long long n, Slot *table,
+                                                           uint64_t table_mask, Counters *ctr)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long key = rec[i].key, tag = rec[i].tag;
+        uint64_t h = mix64(key) & table_mask;
+        unsigned probes = 0;
+        for (;;) {
+            unsigned long long cur = table[h].key;
+            if (cur == kEmpty) {
+                cur = atomicCAS(&table[h].key, kEmpty, key);
+                if (cur == kEmpty) cur = key;
+            }
+            if (cur == key) {
+                if (table[h].tag > tag) atomicMin(&table[h].tag, tag);
+                break;
+            }
+            h = (h + 1) & table_mask;
+            if (++probes > table_mask) { atomicOr(&ctr->err, kErrTableFull); break; }
+        }
+    }
+}
+
+// owner side, pass 2: a received record whose tag is its voxel's minimum is an output point
+__global__ __launch_bounds__(256) void merge_finalize_kernel(const Record *rec, unsigned long long n,
+                                                             const Slot *table, uint64_t table_mask, Counters *ctr,
+                                                             double *out_xyz, uint32_t *out_bgr,
+                                                             unsigned long long *out_key, unsigned long long *out_tag)
+{
+    const unsigned lane = lane_id();
+    const unsigned long long n_round = (n + 63) / 64 * 64;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        bool win = false;
+        Record r;
+        r.key = 0; r.tag = 0; r.x = r.y = r.z = 0; r.bgr = 0; r.pad = 0;
+        if (i < n) {
+            r = rec[i];
+            uint64_t h = mix64(r.key) & table_mask;
+            for (;;) {
+                const unsigned long long cur = table[h].key;
+                if (cur == r.key) { win = table[h].tag == r.tag; break; }
+                if (cur == kEmpty) break;
+                h = (h + 1) & table_mask;
+            }
+        }
+        const unsigned long long m = __ballot(win);
+        if (m != 0) {
+            unsigned long long obase = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if ((int)lane == leader) obase = atomicAdd(&ctr->out_count, (unsigned long long)__popcll(m));
+            obase = __shfl(obase, leader);
+            if (win) {
+                const unsigned long long o = obase + (unsigned)__popcll(m & lanemask_lt());
+                out_xyz[3 * o + 0] = r.x;
+                out_xyz[3 * o + 1] = r.y;
+                out_xyz[3 * o + 2] = r.z;
+                out_bgr[o] = r.bgr;
+                out_key[o] = r.key;
+                out_tag[o] = r.tag;
             }
         }
     }

@@ -34,8 +34,10 @@ EXPORTS = [
     "sfm_fusion_add_keyframe", "sfm_fusion_set_neighbors", "sfm_fusion_run",
     "sfm_fusion_num_points", "sfm_fusion_read_points", "sfm_fusion_get_stats",
     "sfm_fusion_get_frame_counts", "sfm_fusion_last_error", "sfm_fusion_version",
-    "sfm_fusion_set_profiling",
+    "sfm_fusion_set_profiling", "sfm_fusion_set_global_order", "sfm_fusion_partition_counts",
+    "sfm_fusion_export_records", "sfm_fusion_merge",
 ]
+SFM_RECORD_BYTES = 48
 
 
 class FusionParams(C.Structure):
@@ -96,6 +98,10 @@ def load_library():
     L.sfm_fusion_get_stats.argtypes = [vp, C.POINTER(FusionStats)]
     L.sfm_fusion_get_frame_counts.argtypes = [vp, vp, vp]
     L.sfm_fusion_set_profiling.argtypes = [vp, C.c_int]
+    L.sfm_fusion_set_global_order.argtypes = [vp, C.POINTER(u32), u32]
+    L.sfm_fusion_partition_counts.argtypes = [vp, u32, C.POINTER(u64)]
+    L.sfm_fusion_export_records.argtypes = [vp, vp, u64]
+    L.sfm_fusion_merge.argtypes = [vp, vp, u64]
     L.sfm_fusion_last_error.argtypes = [vp]
     L.sfm_fusion_last_error.restype = C.c_char_p
     L.sfm_fusion_version.restype = C.c_char_p
@@ -186,6 +192,22 @@ class FusionContext:
         nb = np.ascontiguousarray(nbrs, dtype=np.uint32)
         self._check(self._L.sfm_fusion_set_neighbors(
             self._h, int(idx), nb.ctypes.data_as(C.POINTER(C.c_uint32)), nb.size))
+
+    def set_global_order(self, order):
+        o = np.ascontiguousarray(order, dtype=np.uint32)
+        self._check(self._L.sfm_fusion_set_global_order(
+            self._h, o.ctypes.data_as(C.POINTER(C.c_uint32)), o.size))
+
+    def partition_counts(self, n_parts: int):
+        counts = (C.c_uint64 * n_parts)()
+        self._check(self._L.sfm_fusion_partition_counts(self._h, n_parts, counts))
+        return [int(x) for x in counts]
+
+    def export_records(self, dst_ptr: int, dst_bytes: int):
+        self._check(self._L.sfm_fusion_export_records(self._h, C.c_void_p(dst_ptr), dst_bytes))
+
+    def merge(self, records_ptr: int, n: int):
+        self._check(self._L.sfm_fusion_merge(self._h, C.c_void_p(records_ptr), n))
 
     def set_profiling(self, enable: bool):
         self._check(self._L.sfm_fusion_set_profiling(self._h, int(bool(enable))))

@@ -49,3 +49,38 @@ def assert_same_cloud(g, c, exact_xyz=True):
     assert st["global_after"] == c.global_after
     for k in ("n_px", "n_gather", "n_acc", "n_hit", "n_vox"):
         assert st[k] == c.counters[k], (k, st[k], c.counters[k])
+
+
+# ---- golden fixtures (tests/golden/*.npz, written by tests/golden/make_golden.py) ----------
+import glob
+import os
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    n = int(z["n_frames"])
+    frames = [dict(depth=z[f"depth_{i}"], bgr=z[f"bgr_{i}"], K=z[f"K_{i}"], T_wk=z[f"T_wk_{i}"],
+                   T_kw=z[f"T_kw_{i}"], nbrs=z[f"nbrs_{i}"].tolist()) for i in range(n)]
+    params = {}
+    for k, v in zip(z["param_names"].tolist(), z["param_values"].tolist()):
+        params[k] = tuple(z["S"].tolist()) if k == "S" else float(v)
+    cnt = dict(zip(("n_px", "n_gather", "n_acc", "n_hit", "n_vox"), (int(x) for x in z["counters"])))
+    want = oracle.Cloud(z["xyz"], z["bgr"], z["key"], z["tag"], z["frame_before"], z["frame_after"],
+                        int(z["global_before"]), int(z["global_after"]), cnt)
+    return frames, params, want
+
+
+def assert_clouds_equal(a, b):
+    """two oracle.Cloud objects, bit-exact"""
+    assert np.array_equal(a.key, b.key) and np.array_equal(a.tag, b.tag) and np.array_equal(a.bgr, b.bgr)
+    assert np.array_equal(np.nan_to_num(a.xyz, nan=1.25e300), np.nan_to_num(b.xyz, nan=1.25e300))
+    assert np.array_equal(a.frame_before, b.frame_before) and np.array_equal(a.frame_after, b.frame_after)
+    assert (a.global_before, a.global_after) == (b.global_before, b.global_after)
+    for k in ("n_px", "n_gather", "n_acc", "n_hit", "n_vox"):
+        assert a.counters[k] == b.counters[k], k

@@ -1,0 +1,166 @@
+"""GPU parity on the edge cases the algorithm has: empty and ragged inputs, keyframes without
+neighbours, zero-depth pathologies (NaN points), mixed intrinsics and sizes, strided host
+images, many neighbours (more than one neighbour per wave), explicit capacities, repeated
+runs, and the C-ABI's error behaviour."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from sfm_amd import fusion, synth
+from helpers import assert_same_cloud, both_params, golden_names, load_golden, run_gpu
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fixtures(name):
+    frames, params, want = load_golden(name)
+    _, gp = both_params(**params)
+    assert_same_cloud(run_gpu(frames, gp), want)
+
+
+def test_plane_pair_with_reference_defaults():
+    frames = scenes.plane_pair()
+    op, gp = both_params()
+    assert_same_cloud(run_gpu(frames, gp), oracle.fuse(frames, op))
+
+
+def test_empty_context_and_empty_images():
+    _, gp = both_params()
+    g = run_gpu([], gp)
+    assert g["key"].shape == (0, 3) and g["stats"]["n_vox"] == 0
+    frames = [scenes.frame(np.zeros((0, 0)), nbrs=[1]), scenes.frame(np.full((6, 9), 30), K=(10, 10, 4, 3), nbrs=[0])]
+    op, gp = both_params()
+    assert_same_cloud(run_gpu(frames, gp), oracle.fuse(frames, op))
+
+
+def test_keyframes_without_neighbours_yield_nothing():
+    frames = [scenes.frame(np.full((20, 30), 35), K=(40, 40, 14.5, 9.5), nbrs=[])]
+    op, gp = both_params()
+    g = run_gpu(frames, gp)
+    assert g["key"].shape[0] == 0
+    assert_same_cloud(g, oracle.fuse(frames, op))
+    # identical poses: the only neighbour is filtered out (KAT-6)
+    f0 = scenes.frame(np.full((12, 16), 30), K=(20, 20, 7.5, 5.5), nbrs=[1])
+    f1 = scenes.frame(np.full((12, 16), 30), K=(20, 20, 7.5, 5.5), nbrs=[0])
+    g = run_gpu([f0, f1], gp)
+    assert g["key"].shape[0] == 0 and g["frame_before"].tolist() == [0, 0]
+
+
+def test_zero_depth_observations_make_nan_points():
+    frames = scenes.plane_pair()
+    frames[1]["depth"] = frames[1]["depth"].copy()
+    frames[1]["depth"][3:30, 4:40:3] = 0
+    op, gp = both_params(T_dist=100.0, voxel_size=0.5)
+    c = oracle.fuse(frames, op)
+    assert np.isnan(c.xyz).any() and (c.key == np.uint64(0x8000000000000000)).any()
+    assert_same_cloud(run_gpu(frames, gp), c)
+
+
+def test_mixed_sizes_intrinsics_and_many_neighbours():
+    rng = np.random.default_rng(3)
+    frames = []
+    n = 11
+    for i in range(n):
+        H, W = (24 + 3 * (i % 3), 33 + 5 * (i % 2))
+        d = (35 + rng.integers(0, 4, size=(H, W))).astype(np.uint16)
+        K = (40.0 + i, 41.0 - 0.5 * i, W / 2 - 0.5 + 0.1 * i, H / 2 - 0.5)
+        frames.append(scenes.frame(d, K=K, C=(0.4 * i, 0.05 * i, 0.02 * i), yaw=0.7 * i,
+                                   nbrs=[j for j in range(n) if j != i]))       # 10 neighbours > 8 waves
+    op, gp = both_params(T_dist=8.0, voxel_size=0.8)
+    c = oracle.fuse(frames, op)
+    assert c.key.shape[0] > 200
+    assert_same_cloud(run_gpu(frames, gp), c)
+
+
+def test_strided_host_rows_and_device_pointers():
+    seq = synth.make_sequence(4, 50, 30, K=(131.25, 131.25, 24.5, 14.5), window=2)
+    frames = seq.frame_dicts()
+    op, gp = both_params(voxel_size=10.0, T_dist=500.0)
+    want = oracle.fuse(frames, op)
+    ctx = fusion.FusionContext(gp)
+    for f in frames:
+        big_d = np.zeros((30, 64), dtype=np.uint16)
+        big_c = np.zeros((30, 70, 3), dtype=np.uint8)
+        big_d[:, :50] = f["depth"]
+        big_c[:, :50] = f["bgr"]
+        ctx.add_keyframe(big_d[:, :50], big_c[:, :50], f["K"], f["T_wk"], f["T_kw"])   # row strides 128 / 210 B
+    for i, f in enumerate(frames):
+        ctx.set_neighbors(i, f["nbrs"])
+    ctx.run()
+    xyz, bgr, key, tag = ctx.read_points()
+    assert np.array_equal(key, want.key) and np.array_equal(tag, want.tag) and np.array_equal(bgr, want.bgr)
+    assert np.array_equal(xyz, want.xyz)
+    ctx.close()
+    import torch
+    ctx = fusion.FusionContext(gp)
+    keep = []
+    for f in frames:
+        d = torch.from_numpy(f["depth"].view(np.int16).copy()).cuda()
+        c = torch.from_numpy(f["bgr"].copy()).cuda()
+        keep += [d, c]
+        ctx.add_keyframe_device(d.data_ptr(), c.data_ptr(), 50, 30, f["K"], f["T_wk"], f["T_kw"])
+    torch.cuda.synchronize()
+    for i, f in enumerate(frames):
+        ctx.set_neighbors(i, f["nbrs"])
+    ctx.run()
+    _, _, key2, tag2 = ctx.read_points()
+    assert np.array_equal(key2, want.key) and np.array_equal(tag2, want.tag)
+    ctx.close()
+
+
+def test_rerun_is_idempotent_and_capacities_grow():
+    seq = synth.make_sequence(6, 96, 72, K=(196.8, 196.8, 47.5, 35.5), window=2)
+    frames = seq.frame_dicts()
+    op, gp = both_params(voxel_size=10.0, T_dist=500.0)
+    want = oracle.fuse(frames, op)
+    ctx = fusion.FusionContext(gp)
+    for f in frames:
+        ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+    for i, f in enumerate(frames):
+        ctx.set_neighbors(i, f["nbrs"])
+    for _ in range(3):
+        ctx.run()
+        xyz, bgr, key, tag = ctx.read_points()
+        assert np.array_equal(key, want.key) and np.array_equal(tag, want.tag) and np.array_equal(xyz, want.xyz)
+    ctx.close()
+    # capacities far too small: explicit ones must fail loudly, automatic ones must grow
+    _, tiny = both_params(voxel_size=10.0, T_dist=500.0, max_points=64)
+    with pytest.raises(fusion.FusionError) as e:
+        run_gpu(frames, tiny)
+    assert e.value.code == fusion.SFM_E_CAPACITY
+    _, tiny = both_params(voxel_size=1.0, T_dist=500.0, table_capacity=1024)
+    with pytest.raises(fusion.FusionError) as e:
+        run_gpu(frames, tiny)
+    assert e.value.code == fusion.SFM_E_TABLE_FULL
+
+
+def test_key_range_overflow_is_reported_not_hidden():
+    frames = scenes.plane_pair()
+    _, gp = both_params(voxel_size=1e-6)      # 40 / 1e-6 = 4e7 voxels from the origin > 2^20
+    with pytest.raises(fusion.FusionError) as e:
+        run_gpu(frames, gp)
+    assert e.value.code == fusion.SFM_E_KEY_RANGE
+
+
+def test_argument_errors():
+    ctx = fusion.FusionContext()
+    f = scenes.plane_pair()[0]
+    ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+    with pytest.raises(fusion.FusionError):
+        ctx.num_points()                       # no run yet
+    ctx.set_neighbors(0, [0])
+    with pytest.raises(fusion.FusionError):
+        ctx.run()                              # own neighbour
+    ctx.set_neighbors(0, [5])
+    with pytest.raises(fusion.FusionError):
+        ctx.run()                              # unknown neighbour
+    ctx.close()
+    far = []
+    for i in range(40):
+        far.append(scenes.frame(np.full((4, 4), 30), K=(5, 5, 1.5, 1.5), C=(0.1 * i, 0, 0),
+                                nbrs=[j for j in range(40) if j != i]))
+    with pytest.raises(fusion.FusionError) as e:
+        run_gpu(far, fusion.default_params())
+    assert e.value.code == fusion.SFM_E_UNSUPPORTED   # > SFM_MAX_NEIGHBORS filtered neighbours
