@@ -7,3 +7,6 @@ mkdir -p sfm_amd/lib build
 hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -Wall \
   -save-temps=obj sfm_amd/csrc/fusion_capi.hip -o build/libsfm_fusion.so "$@"
 cp build/libsfm_fusion.so sfm_amd/lib/libsfm_fusion.so
+# C++ facade example (host-only code over the C ABI); run by tests/test_gpu_cpp_facade.py
+g++ -std=c++17 -O2 -Wall sfm_amd/cpp/facade_example.cpp -Lsfm_amd/lib -lsfm_fusion \
+  -Wl,-rpath,'$ORIGIN/../lib' -o sfm_amd/cpp/facade_example
