@@ -38,15 +38,20 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def fuse_bytes(st):
-    """Algorithmic bytes of the per-keyframe kernels (SURVEY.md 8d terms that those kernels
-    move): depth u16 + mask u8 per pixel, 2 B per neighbour depth gather, 3 B colour and one
-    16-B slot read+write per accepted pixel, 1 B per mask store."""
-    return 3 * st["n_px"] + 2 * st["n_gather"] + 3 * st["n_acc"] + st["n_hit"] + 32 * st["n_acc"]
+def observe_bytes(st):
+    """Algorithmic bytes of observe_frame_kernel, the dominant kernel (SURVEY.md 8d terms that
+    it moves): 2 B per neighbour depth gather, 3 B colour and one 16-B slot read+write (its
+    record hand-off to the voxel table) per accepted pixel, 1 B per mask store."""
+    return 2 * st["n_gather"] + 3 * st["n_acc"] + st["n_hit"] + 32 * st["n_acc"]
+
+
+def scan_bytes(st):
+    """scan_frame_kernel: depth u16 + mask u8 per pixel."""
+    return 3 * st["n_px"]
 
 
 def total_bytes(st):
-    return fuse_bytes(st) + 27 * st["n_vox"]
+    return scan_bytes(st) + observe_bytes(st) + 27 * st["n_vox"]
 
 
 def main():
@@ -127,7 +132,7 @@ def main():
         dist.all_reduce(t)
         n_points = int(t.item())
 
-    # roofline of the dominant kernel (fuse_frame_kernel): one extra, untimed, run with
+    # roofline of the dominant kernel (observe_frame_kernel): one extra, untimed, run with
     # per-dispatch start/stop events on the library's stream
     ctx.set_profiling(True)
     ctx.run()
@@ -135,7 +140,8 @@ def main():
     ctx.set_profiling(False)
     launches = max(1, pst["fuse_kernel_launches"])
     avg_launch_s = pst["fuse_kernel_sum_ms"] * 1e-3 / launches
-    bytes_per_launch = fuse_bytes(pst) / launches
+    bytes_per_launch = observe_bytes(pst) / launches
+    scan_avg_s = pst["scan_kernel_sum_ms"] * 1e-3 / launches
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -171,7 +177,7 @@ def main():
         "device_ms_per_step_rank0": st["last_run_ms"],
         "roofline": {
             "bound": "hbm",
-            "kernel": "fuse_frame_kernel",
+            "kernel": "observe_frame_kernel",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -180,6 +186,8 @@ def main():
             "bytes_per_launch": bytes_per_launch,
             "avg_launch_us": avg_launch_s * 1e6,
             "launches_per_step": launches,
+            "scan_kernel": {"avg_launch_us": scan_avg_s * 1e6, "bytes_per_launch": scan_bytes(pst) / launches,
+                            "achieved": scan_bytes(pst) / launches / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0},
             "whole_step_frac": total_bytes(st) / (st["last_run_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             if st["last_run_ms"] > 0 else None,
         },

@@ -80,8 +80,9 @@ typedef struct sfm_fusion_stats {
     double frame_kernels_ms;/* device time between first and last per-frame kernel */
     /* filled when sfm_fusion_set_profiling(ctx,1): per-dispatch start/stop timestamps of the
      * per-keyframe kernel (same clock rocprofv3 --kernel-trace reads) */
-    uint64_t fuse_kernel_launches;
-    double fuse_kernel_sum_ms;
+    uint64_t fuse_kernel_launches;   /* observe_frame_kernel dispatches (one per keyframe) */
+    double fuse_kernel_sum_ms;       /* sum of their durations */
+    double scan_kernel_sum_ms;       /* sum of the scan_frame_kernel durations */
 } sfm_fusion_stats;
 
 void sfm_fusion_default_params(sfm_fusion_params *p);

@@ -3,7 +3,7 @@
 // computes needs a HIP device and fails with SFM_E_HIP otherwise.
 //
 // Stream plan of one run (DESIGN.md "Streams"):
-//   stream A (caller's or private): memsets, then fuse_frame_kernel per keyframe, strictly in
+//   stream A (caller's or private): memsets, then scan_frame_kernel + observe_frame_kernel per keyframe, strictly in
 //            order -- the visibility masks make this a chain.
 //   stream B (private): table_group_kernel per group of 32 keyframes, each waiting on the event
 //            of the group's last keyframe kernel; it overlaps the chain on stream A.
@@ -66,19 +66,23 @@ struct sfm_fusion_ctx {
     DevBuf<uint8_t> d_masks;
     DevBuf<Slot> d_table;
     DevBuf<unsigned long long> d_mark;
-    DevBuf<unsigned long long> d_list_key, d_list_tag, d_out_key, d_out_tag;
+    DevBuf<unsigned long long> d_list_key, d_list_tag, d_out_key, d_out_tag, d_cand;
     DevBuf<double> d_list_xyz, d_out_xyz;
     DevBuf<uint32_t> d_list_bgr, d_out_bgr;
     DevBuf<unsigned long long> d_fbefore, d_fafter, d_group_end;
+    DevBuf<uint32_t> d_qpix;           // survivor queue of the keyframe in flight
+    DevBuf<double> d_qpw;
+    DevBuf<unsigned int> d_qcount;     // [n_frames][kQueueShards*16] queue cursors
+    uint32_t q_shard_cap = 0;
+    int n_cu = 256;
     // one allocation: Counters | cursors | stat shards (zeroed by a single memset per run)
     unsigned char *d_small = nullptr;
     HostCounters *h_small = nullptr;  // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_init = nullptr, ev_b_done = nullptr;
     std::vector<hipEvent_t> gev;  // one per keyframe group
-    unsigned long long *stamp_dev = nullptr;
-    uint32_t stamp_tiles = 0;
-    uint32_t max_waves = 4;          // waves per fuse_frame workgroup (SFM_FUSE_WAVES overrides)
+    uint32_t max_waves = 4;          // waves per observe workgroup (SFM_FUSE_WAVES overrides)
+    uint32_t waves_per_cu = 28;      // resident observe waves per CU (SFM_FUSE_RESIDENT overrides)
     bool profile = false;         // per-launch start/stop events on the frame kernels
     std::vector<hipEvent_t> kev;  // 2 per keyframe when profiling
 
@@ -271,6 +275,12 @@ int build_layout(sfm_fusion_ctx *c)
     if ((rc = ensure(c, c->d_fbefore, n))) return rc;
     if ((rc = ensure(c, c->d_fafter, n))) return rc;
     if ((rc = ensure(c, c->d_group_end, (n + kGroup - 1) / kGroup * kListShards * 8))) return rc;
+    uint64_t max_tiles = 1;
+    for (auto &f : c->frames) max_tiles = std::max<uint64_t>(max_tiles, ((uint64_t)f.W * f.H + kTile - 1) / kTile);
+    c->q_shard_cap = (uint32_t)((max_tiles + kQueueShards - 1) / kQueueShards * kTile);
+    if ((rc = ensure(c, c->d_qpix, (uint64_t)kQueueShards * c->q_shard_cap))) return rc;
+    if ((rc = ensure(c, c->d_qpw, 3ull * kQueueShards * c->q_shard_cap))) return rc;
+    if ((rc = ensure(c, c->d_qcount, (uint64_t)n * kQueueShards * 16))) return rc;
     if (!pack.empty())
         HIP_TRY(c, hipMemcpy(c->d_nbrpack.p, pack.data(), pack.size() * sizeof(FrameDev), hipMemcpyHostToDevice));
     c->layout_dirty = false;
@@ -289,6 +299,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     if ((rc = ensure(c, c->d_list_tag, list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_xyz, 3 * list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_bgr, list_cap))) return rc;
+    if ((rc = ensure(c, c->d_cand, list_cap))) return rc;
     const size_t n_groups = (n + kGroup - 1) / kGroup;
     while (c->gev.size() < n_groups) {
         hipEvent_t e;
@@ -296,7 +307,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
         c->gev.push_back(e);
     }
     if (c->profile)
-        while (c->kev.size() < 2 * n) {
+        while (c->kev.size() < 4 * n) {
             hipEvent_t e;
             HIP_TRY(c, hipEventCreate(&e));
             c->kev.push_back(e);
@@ -310,6 +321,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     if (n) {
         HIP_TRY(c, hipMemsetAsync(c->d_fbefore.p, 0, n * sizeof(unsigned long long), sa));
         HIP_TRY(c, hipMemsetAsync(c->d_fafter.p, 0, n * sizeof(unsigned long long), sa));
+        HIP_TRY(c, hipMemsetAsync(c->d_qcount.p, 0, n * kQueueShards * 16 * sizeof(unsigned int), sa));
     }
     HIP_TRY(c, hipEventRecord(c->ev_init, sa));
     HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_init, 0));
@@ -323,6 +335,12 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     list.cursor = dev_cursor(c);
     list.group_end = c->d_group_end.p;
 
+    QueueDev q;
+    q.pix = c->d_qpix.p;
+    q.pw = c->d_qpw.p;
+    q.shard_cap = c->q_shard_cap;
+    q.count = nullptr;
+    ScanArgs sc;
     FuseArgs a;
     a.list = list;
     a.stat = dev_stat(c);
@@ -344,40 +362,37 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     t.ctr = dev_ctr(c);
     t.frame_before = c->d_fbefore.p;
     t.frame_after = c->d_fafter.p;
+    t.cand = c->d_cand.p;
 
     HIP_TRY(c, hipEventRecord(c->ev[1], sa));
     for (size_t i = 0; i < n; i++) {  // :48-52, strictly in order
         const HostFrame &f = c->frames[i];
         const uint64_t px = (uint64_t)f.W * f.H;
-        // a keyframe without pixels still runs one (empty) workgroup so that its list
-        // boundary frame_end[] is published
-        const uint32_t nw = std::min<uint32_t>(std::max<uint32_t>(f.n_filtered, 1), c->max_waves);
-        // 64-pixel sub-tiles, nw of them (one per wave, strided by the grid) per workgroup
-        const uint64_t nsub = (px + kWave - 1) / kWave;
-        const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, (nsub + nw - 1) / nw);
-        const size_t lds = fuse_lds_bytes(f.n_filtered, nw);
-        a.f = (uint32_t)i;
-        a.F = c->h_frames[i];
-#ifdef SFM_STAMPS
-        {   // diagnostic build: stamp one keyframe's workgroups and dump them after the run
-            static unsigned long long *d_st = nullptr;
-            const char *sf = std::getenv("SFM_STAMP_FRAME");
-            a.stamps = nullptr;
-            if (sf && (size_t)std::atoi(sf) == i) {
-                if (!d_st) (void)hipMalloc(&d_st, 8 * 8 * 65536);
-                (void)hipMemsetAsync(d_st, 0, 8 * 8 * 65536, sa);
-                a.stamps = d_st;
-                c->stamp_dev = d_st;
-                c->stamp_tiles = tiles;
+        if (px) {
+            const uint32_t nw = std::min<uint32_t>(std::max<uint32_t>(f.n_filtered, 1), c->max_waves);
+            q.count = c->d_qcount.p + i * kQueueShards * 16;
+            sc.F = c->h_frames[i];
+            sc.q = q;
+            sc.P = a.P;
+            a.F = c->h_frames[i];
+            a.q = q;
+            const FrameDev *nbp = c->d_nbrpack.p + a.F.nbr_begin;
+            const uint32_t tiles = (uint32_t)((px + kTile - 1) / kTile);
+            // every chunk of 64 survivors gets a workgroup; beyond what fits on the chip at
+            // once the workgroups loop
+            const uint32_t resident = (uint32_t)c->n_cu * std::max<uint32_t>(1, c->waves_per_cu / nw);
+            const uint32_t wgs = (uint32_t)std::min<uint64_t>((px + kWave - 1) / kWave, resident);
+            const size_t lds = fuse_lds_bytes(f.n_filtered);
+            if (c->profile) {
+                hipExtLaunchKernelGGL(scan_frame_kernel, dim3(tiles), dim3(kWave), 0, sa, c->kev[4 * i],
+                                      c->kev[4 * i + 1], 0, sc);
+                hipExtLaunchKernelGGL(observe_frame_kernel, dim3(wgs), dim3(nw * kWave), lds, sa,
+                                      c->kev[4 * i + 2], c->kev[4 * i + 3], 0, nbp, a);
+            } else {
+                hipLaunchKernelGGL(scan_frame_kernel, dim3(tiles), dim3(kWave), 0, sa, sc);
+                hipLaunchKernelGGL(observe_frame_kernel, dim3(wgs), dim3(nw * kWave), lds, sa, nbp, a);
             }
         }
-#endif
-        const FrameDev *nbp = c->d_nbrpack.p + a.F.nbr_begin;
-        if (c->profile)
-            hipExtLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(nw * kWave), lds, sa, c->kev[2 * i],
-                                  c->kev[2 * i + 1], 0, nbp, a);
-        else
-            hipLaunchKernelGGL(fuse_frame_kernel, dim3(tiles), dim3(nw * kWave), lds, sa, nbp, a);
         if (i % kGroup == kGroup - 1 || i + 1 == n) {
             const size_t g = i / kGroup;
             // list boundaries of the group: snapshot of the append cursors, in stream order
@@ -406,38 +421,30 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     }
     *err_bits = err;
     if (err) return SFM_OK;  // caller decides: grow and retry, or report
-    if ((rc = ensure(c, c->d_out_key, n_list))) return rc;
-    if ((rc = ensure(c, c->d_out_tag, n_list))) return rc;
-    if ((rc = ensure(c, c->d_out_xyz, 3 * n_list))) return rc;
-    if ((rc = ensure(c, c->d_out_bgr, n_list))) return rc;
-    if (n_list) {
+    const uint64_t n_cand = c->h_small->ctr.cand_count;
+    (void)n_list;
+    if ((rc = ensure(c, c->d_out_key, n_cand))) return rc;
+    if ((rc = ensure(c, c->d_out_tag, n_cand))) return rc;
+    if ((rc = ensure(c, c->d_out_xyz, 3 * n_cand))) return rc;
+    if ((rc = ensure(c, c->d_out_bgr, n_cand))) return rc;
+    if (n_cand) {
         FinalizeArgs fa;
         fa.table = c->d_table.p;
         fa.table_mask = table_cap - 1;
         fa.list = list;
+        fa.cand = c->d_cand.p;
         fa.ctr = dev_ctr(c);
         fa.out_xyz = c->d_out_xyz.p;
         fa.out_bgr = c->d_out_bgr.p;
         fa.out_key = c->d_out_key.p;
         fa.out_tag = c->d_out_tag.p;
-        const uint64_t per_shard = (n_list / kListShards + 255) / 256 + 1;
-        const uint32_t bx = (uint32_t)std::min<uint64_t>(per_shard, 256);
-        hipLaunchKernelGGL(finalize_kernel, dim3(bx, kListShards), dim3(256), 0, sa, fa);
+        const uint32_t bx = (uint32_t)std::min<uint64_t>((n_cand + 255) / 256, 4096);
+        hipLaunchKernelGGL(finalize_kernel, dim3(bx), dim3(256), 0, sa, fa);
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipEventRecord(c->ev[3], sa));
     HIP_TRY(c, hipMemcpyAsync(c->h_small, c->d_small, kSmallBytes, hipMemcpyDeviceToHost, sa));
     HIP_TRY(c, hipStreamSynchronize(sa));
-#ifdef SFM_STAMPS
-    if (c->stamp_dev && std::getenv("SFM_STAMP_FILE")) {
-        std::vector<unsigned long long> h((size_t)c->stamp_tiles * 8);
-        (void)hipMemcpy(h.data(), c->stamp_dev, h.size() * 8, hipMemcpyDeviceToHost);
-        if (FILE *fp = std::fopen(std::getenv("SFM_STAMP_FILE"), "wb")) {
-            std::fwrite(h.data(), 8, h.size(), fp);
-            std::fclose(fp);
-        }
-    }
-#endif
     return SFM_OK;
 }
 
@@ -478,6 +485,14 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
         const int v = std::atoi(e);
         if (v >= 1 && v <= kMaxWaves) c->max_waves = (uint32_t)v;
     }
+    if (const char *e = std::getenv("SFM_FUSE_RESIDENT")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64) c->waves_per_cu = (uint32_t)v;
+    }
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v;
+    }
     std::memset(&c->stats, 0, sizeof c->stats);
     bool ok = hipSetDevice(device) == hipSuccess;
     if (ok && stream) {
@@ -512,7 +527,8 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     }
     release(c->d_part); release(c->d_gorder); release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
     release(c->d_mark); release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
-    release(c->d_out_tag); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
+    release(c->d_out_tag); release(c->d_cand); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
+    release(c->d_qpix); release(c->d_qpw); release(c->d_qcount);
     release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_group_end);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -660,9 +676,13 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     st.frame_kernels_ms = ms;
     st.fuse_kernel_launches = 0;
     st.fuse_kernel_sum_ms = 0;
+    st.scan_kernel_sum_ms = 0;
     if (c->profile) {
         for (size_t i = 0; i < n; i++) {
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[2 * i], c->kev[2 * i + 1]));
+            if ((uint64_t)c->frames[i].W * c->frames[i].H == 0) continue;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * i], c->kev[4 * i + 1]));
+            st.scan_kernel_sum_ms += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * i + 2], c->kev[4 * i + 3]));
             st.fuse_kernel_sum_ms += ms;
             st.fuse_kernel_launches++;
         }

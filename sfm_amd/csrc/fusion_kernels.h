@@ -5,10 +5,10 @@
 // clang -O3, no -march => SSE2, no FMA; reconstruction/CMakeLists.txt:3-5).  The Eigen
 // evaluation orders that matter are spelled out next to each function.
 //
-// Three kernels:
-//   fuse_frame_kernel   one launch per keyframe, in order (the visibility masks chain the
-//                       keyframes).  Workgroup = one 256-pixel tile, one wave
-//                       per (group of) neighbour keyframe(s).
+// Kernels:
+//   scan_frame_kernel, observe_frame_kernel
+//                       two launches per keyframe, in order (the visibility masks chain the
+//                       keyframes); see "the per-keyframe kernels" below.
 //   table_group_kernel  first-wins voxel filter for a group of <= 32 keyframes: open-addressing
 //                       hash in HBM, atomicCAS key claim + atomicMin order tag.  Runs on a
 //                       second stream, off the keyframe chain.
@@ -75,6 +75,7 @@ struct StatShard {  // one 64-byte line per shard
 struct Counters {
     unsigned long long out_count;
     unsigned long long table_used;
+    unsigned long long cand_count;  // entries of the winner-candidate index list
     unsigned int err;
     unsigned int max_probe;
 };
@@ -93,27 +94,6 @@ struct ListDev {
     // keyframe of each group (a 1-KiB device-to-device copy), i.e. the groups' list boundaries
     const unsigned long long *group_end;
 };
-
-struct FuseArgs {
-    FrameDev F;                // the keyframe being fused (by value: arrives with the kernargs)
-    ListDev list;
-    StatShard *stat;           // [kStatShards]
-    DevParams P;
-    uint32_t f;
-#ifdef SFM_STAMPS
-    unsigned long long *stamps;  // diagnostic build only: [tiles][8] s_memrealtime values
-#endif
-};
-
-#ifdef SFM_STAMPS
-#define SFM_STAMP(i)                                                                   \
-    do {                                                                               \
-        if (a.stamps && (w == 0 || (i) == 5) && lane == 0)                             \
-            a.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#else
-#define SFM_STAMP(i) do {} while (0)
-#endif
 
 // ---- exact arithmetic helpers ---------------------------------------------------------
 
@@ -224,34 +204,143 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
     return v;
 }
 
-// ---- the per-keyframe kernel ------------------------------------------------------------
+// ---- the per-keyframe kernels ------------------------------------------------------------
 //
-// Workgroup = NW waves, 64*NW pixels.  Stages:
-//   A  wave w scans the 64-pixel sub-tile blockIdx.x + w*gridDim.x (coalesced rows; a
-//      workgroup's pixels are spread over the image so dense and sparse regions average out)
-//      and ballot/popcount-compacts its live pixels into the shared queue s_q
-//   B  live chunks dealt round-robin to the waves: covariance gate + back-projection; the
-//      survivors are re-compacted into s_q2 (pixel, world point)
-//   C  per 64-survivor chunk: wave w re-observes the chunk in neighbours w, w+NW, ...;
-//      results meet in LDS; ONE wave (rotating with the workgroup id, so that the serial part
-//      spreads over the four SIMDs) takes the decision, scatters the masks and writes records.
+// Two launches per keyframe, strictly in keyframe order (the visibility masks chain the
+// keyframes):
 //
-// LDS per workgroup (dynamic, K = filtered neighbours of this keyframe):
+//   scan_frame_kernel     one wave per 256-pixel tile: coalesced ushort4/uchar4 loads,
+//                         ballot/popcount compaction of live pixels (:100-101), covariance gate
+//                         (:136-140) and back-projection (:143-144) on dense batches, survivors
+//                         (pixel, world point) appended to the keyframe's queue in HBM.
+//   observe_frame_kernel  one workgroup per 64 queued survivors -- every chunk is full, every
+//                         workgroup does the same amount of work whatever the live-pixel
+//                         distribution over the image is.  Wave w re-observes the chunk in
+//                         neighbours w, w+NW, ...; the waves meet in LDS; every wave scatters the
+//                         masks of its own neighbours; one wave forms the fused point and the record.
+
+// Survivor queue of one keyframe: kQueueShards independent append regions (one cursor each on
+// its own 64-B line), refilled by every scan and drained by the observe kernel that follows.
+constexpr int kQueueShards = 16;
+
+struct QueueDev {
+    uint32_t *pix;        // [kQueueShards][shard_cap]
+    double *pw;           // [3][kQueueShards * shard_cap]  world point, SoA
+    uint32_t shard_cap;   // entries per shard (>= 256 * ceil(tiles / kQueueShards))
+    unsigned int *count;  // this keyframe's cursors: [kQueueShards * 16] (stride 16 u32)
+};
+
+struct ScanArgs {
+    FrameDev F;
+    QueueDev q;
+    DevParams P;
+};
+
+__global__ __launch_bounds__(kWave) void scan_frame_kernel(ScanArgs a)
+{
+    __shared__ uint32_t s_pix[kTile];
+    __shared__ uint16_t s_d[kTile];
+    __shared__ uint32_t s_spix[kTile];
+    __shared__ double s_pw[3 * kTile];
+    const unsigned lane = lane_id();
+    const FrameDev &F = a.F;
+    const DevParams &P = a.P;
+    const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
+    // -- live pixels of the tile (:100-101); a keyframe without neighbours yields nothing (:180)
+    uint32_t qn = 0;
+    {
+        const uint32_t i0 = blockIdx.x * kTile + lane * kPxPerLane;
+        uint16_t d[kPxPerLane];
+        uint8_t mk[kPxPerLane];
+        if (i0 + kPxPerLane <= npx) {
+            const ushort4 dv = *reinterpret_cast<const ushort4 *>(F.depth + i0);
+            const uchar4 mv = *reinterpret_cast<const uchar4 *>(F.mask + i0);
+            d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
+            mk[0] = mv.x; mk[1] = mv.y; mk[2] = mv.z; mk[3] = mv.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kPxPerLane; j++) {
+                const bool in = i0 + j < npx;
+                d[j] = in ? F.depth[i0 + j] : (uint16_t)0;
+                mk[j] = in ? F.mask[i0 + j] : (uint8_t)255;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kPxPerLane; j++) {
+            const bool live = (mk[j] == 0) && (d[j] > 0) && (F.nbr_count > 0);
+            const unsigned long long m = __ballot(live);
+            if (live) {
+                const unsigned pos = qn + (unsigned)__popcll(m & lanemask_lt());
+                s_pix[pos] = i0 + j;
+                s_d[pos] = d[j];
+            }
+            qn += (unsigned)__popcll(m);
+        }
+    }
+    if (qn == 0) return;
+    __syncthreads();  // one-wave workgroup: orders the LDS writes above before the reads below
+    // -- covariance gate + back-projection on dense batches of 64
+    uint32_t ns = 0;
+    for (uint32_t c0 = 0; c0 < qn; c0 += kWave) {
+        const bool act = c0 + lane < qn;
+        const uint32_t pix = act ? s_pix[c0 + lane] : 0u;
+        const uint32_t draw = act ? (uint32_t)s_d[c0 + lane] : 1u;
+        const double dsrc = (double)draw;
+        const int u = (int)(pix % (uint32_t)F.W);
+        const int v = (int)(pix / (uint32_t)F.W);
+        const double tr = cov_trace_tab(P, u, v, F.ctab + 4 * (size_t)draw);  // :136
+        const bool pass = act && !(tr > P.T_cov);                             // :138
+        const unsigned long long m = __ballot(pass);
+        if (pass) {
+            const double xn = F.xtab[u];                                      // pinhole.cpp:12
+            const double yn = F.ytab[v];
+            const double pcx = xn * dsrc, pcy = yn * dsrc, pcz = dsrc;        // :15-19
+            const unsigned pos = ns + (unsigned)__popcll(m & lanemask_lt());
+            s_spix[pos] = pix;
+            s_pw[pos] = row_apply(F.Twk, 0, pcx, pcy, pcz);                   // :144
+            s_pw[kTile + pos] = row_apply(F.Twk, 1, pcx, pcy, pcz);
+            s_pw[2 * kTile + pos] = row_apply(F.Twk, 2, pcx, pcy, pcz);
+        }
+        ns += (unsigned)__popcll(m);
+    }
+    if (ns == 0) return;
+    __syncthreads();
+    // -- one reservation per tile, then a coalesced copy into the keyframe's queue
+    const uint32_t shard = blockIdx.x % kQueueShards;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&a.q.count[shard * 16], ns);
+    base = __shfl(base, 0);
+    const size_t plane = (size_t)kQueueShards * a.q.shard_cap;
+    for (uint32_t i = lane; i < ns; i += kWave) {
+        const size_t o = (size_t)shard * a.q.shard_cap + base + i;
+        a.q.pix[o] = s_spix[i];
+        a.q.pw[o] = s_pw[i];
+        a.q.pw[plane + o] = s_pw[kTile + i];
+        a.q.pw[2 * plane + o] = s_pw[2 * kTile + i];
+    }
+}
+
+// LDS per workgroup of observe_frame_kernel (dynamic, K = filtered neighbours):
 //   s_obs  [K][4][64] double   per neighbour, per lane: q*(1/w) (x,y,z) and 1/w
 //   s_hit  [K][64]    u32      re-observed pixel in the neighbour
 //   s_kept [K], s_close[K] u64 ballots: observation kept (:204) / within T_dist (:224)
-//   s_pw   [3][Q]     double   world point of each survivor          (Q = 64*NW pixels)
-//   s_base u64, s_cnt[4] u32, s_qpix[Q] u32, s_q2pix[Q] u32, s_qd[Q] u16
-__host__ __device__ inline size_t fuse_lds_bytes(uint32_t K, uint32_t NW)
+__host__ __device__ inline size_t fuse_lds_bytes(uint32_t K)
 {
-    const size_t Q = (size_t)NW * kWave;
-    return (size_t)K * (4 * 64 * 8 + 64 * 4 + 16) + 3 * Q * 8 + 8 + 16 + Q * 4 + Q * 4 + Q * 2;
+    return (size_t)K * (4 * 64 * 8 + 64 * 4 + 16) + 16;
 }
 
-// process_pixel + geometric_check (dense_reconstruction.cpp:126-234).
+struct FuseArgs {
+    FrameDev F;                // the keyframe being fused (by value: arrives with the kernargs)
+    QueueDev q;
+    ListDev list;
+    StatShard *stat;           // [kStatShards]
+    DevParams P;
+};
+
+// geometric_check + the tail of process_pixel (dense_reconstruction.cpp:146-175, :177-234).
 // nbp = this keyframe's filtered neighbours, one FrameDev copy each, in neighbour order
 // (never written by any kernel: __restrict__ keeps the reads on the scalar path).
-__global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
+__global__ __launch_bounds__(kMaxWaves * kWave) void observe_frame_kernel(
     const FrameDev *__restrict__ nbp, FuseArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -266,105 +355,48 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
     uint32_t *s_hit = reinterpret_cast<uint32_t *>(s_obs + (size_t)K * 256);
     unsigned long long *s_kept = reinterpret_cast<unsigned long long *>(s_hit + (size_t)K * 64);
     unsigned long long *s_close = s_kept + K;
-    const uint32_t Q = NW * kWave;
-    double *s_pw = reinterpret_cast<double *>(s_close + K);
-    unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_pw + 3 * Q);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_base + 1);  // gathers, hits, survivors, live
-    uint32_t *s_qpix = s_cnt + 4;
-    uint32_t *s_q2pix = s_qpix + Q;
-    uint16_t *s_qd = reinterpret_cast<uint16_t *>(s_q2pix + Q);
 
-    const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
-    const uint32_t shard = blockIdx.x % kListShards;
-    SFM_STAMP(0);
-#if SFM_ABLATE_EXIT == 1
-    return;
-#endif
-
-    // -- stage A: sub-tile scan + ballot/popcount compaction of live pixels (:100-101)
-    if (w == 0 && lane < 4) s_cnt[lane] = 0;
-    __syncthreads();
-    {
-        const uint32_t t = blockIdx.x + w * gridDim.x;
-        const uint32_t i = t * kWave + lane;
-        uint16_t d = 0;
-        bool live = false;
-        if (i < npx && K > 0) {                                          // K==0: :180 rejects all
-            d = F.depth[i];
-            live = (F.mask[i] == 0) && (d > 0);
-        }
-        const unsigned long long m = __ballot(live);
-        if (m != 0) {
-            const int leader = __ffsll((long long)m) - 1;
-            unsigned base = 0;
-            if ((int)lane == leader) base = atomicAdd(&s_cnt[3], (unsigned)__popcll(m));
-            base = __shfl(base, leader);
-            if (live) {
-                const unsigned pos = base + (unsigned)__popcll(m & lanemask_lt());
-                s_qpix[pos] = i;
-                s_qd[pos] = d;
+    // chunks of 64 survivors, shard after shard
+    uint32_t cnt[kQueueShards];
+    uint32_t total_chunks = 0;
+#pragma unroll
+    for (int s = 0; s < kQueueShards; s++) {
+        cnt[s] = a.q.count[s * 16];
+        total_chunks += (cnt[s] + kWave - 1) / kWave;
+    }
+    const size_t plane = (size_t)kQueueShards * a.q.shard_cap;
+    unsigned c_gather = 0, c_hit = 0;
+    for (uint32_t c = blockIdx.x; c < total_chunks; c += gridDim.x) {
+        uint32_t shard = 0, j = c, n_in = 0;
+#pragma unroll
+        for (int s = 0; s < kQueueShards; s++) {
+            const uint32_t nc = (cnt[s] + kWave - 1) / kWave;
+            if (n_in == 0) {
+                if (j < nc) { shard = s; n_in = min(cnt[s] - j * kWave, (uint32_t)kWave); }
+                else j -= nc;
             }
         }
-    }
-    __syncthreads();
-    SFM_STAMP(1);
-    const uint32_t qn = s_cnt[3];
-    if (qn == 0) return;  // uniform over the workgroup
-
-    // -- stage B: covariance gate + back-projection, chunks dealt to the waves
-    for (uint32_t c0 = w * kWave; c0 < qn; c0 += NW * kWave) {
-        const bool act = c0 + lane < qn;
-        const uint32_t pix = act ? s_qpix[c0 + lane] : 0u;
-        const uint32_t draw = act ? (uint32_t)s_qd[c0 + lane] : 1u;
-        const double dsrc = (double)draw;
-        const int u = (int)(pix % (uint32_t)F.W);
-        const int v = (int)(pix / (uint32_t)F.W);
-        const double tr = cov_trace_tab(P, u, v, F.ctab + 4 * (size_t)draw);  // :136
-        const bool pass = act && !(tr > P.T_cov);                        // :138
-        const unsigned long long m = __ballot(pass);
-        if (m != 0) {
-            const int leader = __ffsll((long long)m) - 1;
-            unsigned base = 0;
-            if ((int)lane == leader) base = atomicAdd(&s_cnt[2], (unsigned)__popcll(m));
-            base = __shfl(base, leader);
-            if (pass) {
-                const double xn = F.xtab[u];                             // pinhole.cpp:12
-                const double yn = F.ytab[v];
-                const double pcx = xn * dsrc, pcy = yn * dsrc, pcz = dsrc;  // :15-19
-                const unsigned pos = base + (unsigned)__popcll(m & lanemask_lt());
-                s_q2pix[pos] = pix;
-                s_pw[pos] = row_apply(F.Twk, 0, pcx, pcy, pcz);          // :144
-                s_pw[Q + pos] = row_apply(F.Twk, 1, pcx, pcy, pcz);
-                s_pw[2 * Q + pos] = row_apply(F.Twk, 2, pcx, pcy, pcz);
-            }
-        }
-    }
-    __syncthreads();
-    SFM_STAMP(2);
-    const uint32_t n2 = s_cnt[2];
-    if (n2 == 0) return;  // uniform
-    // one reservation per workgroup: an entry per surviving pixel.  Issued now, consumed after
-    // the first chunk's neighbour work, so its round trip hides under the arithmetic.
-    unsigned long long base_r = 0;
-    if (w == 0 && lane == 0) base_r = atomicAdd(&a.list.cursor[shard * 8], (unsigned long long)n2);
-
-    for (uint32_t c0 = 0; c0 < n2; c0 += kWave) {
-        const bool act = c0 + lane < n2;
-        const unsigned p3 = (blockIdx.x + (c0 >> 6)) % NW;  // wave that finishes this chunk
+        const bool act = lane < n_in;
+        const unsigned p3 = c % NW;  // the wave that finishes this chunk (spreads over the SIMDs)
+        const size_t qi = (size_t)shard * a.q.shard_cap + (size_t)j * kWave + lane;
         double pwx = 0, pwy = 0, pwz = 0;
         uint32_t pix = 0, col = 0;
+        unsigned long long base_r = 0;
         if (act) {
-            pwx = s_pw[c0 + lane];
-            pwy = s_pw[Q + c0 + lane];
-            pwz = s_pw[2 * Q + c0 + lane];
-            if (w == p3) {                                               // :170, features.cpp:76-80
-                pix = s_q2pix[c0 + lane];
+            pwx = a.q.pw[qi];
+            pwy = a.q.pw[plane + qi];
+            pwz = a.q.pw[2 * plane + qi];
+        }
+        if (w == p3) {
+            // list space for the chunk: issued now, consumed after the neighbour work
+            if (lane == 0) base_r = atomicAdd(&a.list.cursor[(c % kListShards) * 8], (unsigned long long)n_in);
+            if (act) {                                                   // :170, features.cpp:76-80
+                pix = a.q.pix[qi];
                 const uint8_t *cp = F.bgr + 3ull * pix;
                 col = (uint32_t)cp[0] | ((uint32_t)cp[1] << 8) | ((uint32_t)cp[2] << 16);
             }
         }
         // wave w re-observes the chunk in neighbours w, w+NW, ...  (:187-216)
-        unsigned n_gather = 0;
         for (uint32_t k = w; k < K; k += NW) {
             const FrameDev &L = nbp[k];
             bool kept = false, close = false, vis = false;
@@ -407,28 +439,33 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
             }
             const unsigned long long mk_ = __ballot(kept);
             const unsigned long long mc_ = __ballot(close);
-            n_gather += (unsigned)__popcll(__ballot(vis));
+            c_gather += (unsigned)__popcll(__ballot(vis));
             if (lane == 0) {
                 s_kept[k] = mk_;
                 s_close[k] = mc_;
             }
         }
-        if (lane == 0) {
-            if (n_gather) atomicAdd(&s_cnt[0], n_gather);
-            if (w == 0 && c0 == 0) *s_base = base_r;
-        }
-        if (c0 == 0) SFM_STAMP(3);
         __syncthreads();
-        if (c0 == 0) SFM_STAMP(4);
-        // decision, mask scatter, weighted fusion, record: one wave per chunk
+        // every wave: the decision (:218, :229) from the ballots ...
+        unsigned n_obs = 0, n_close = 0;
+        for (uint32_t k = 0; k < K; k++) {
+            n_obs += (unsigned)((s_kept[k] >> lane) & 1ull);
+            n_close += (unsigned)((s_close[k] >> lane) & 1ull);
+        }
+        bool ok = act && n_obs >= 1;                                         // :218
+        if ((double)n_close < (double)n_obs * P.close_frac) ok = false;      // :229
+        // ... and the mask scatter of its own neighbours (:152-154); masks of already-processed
+        // keyframes are never read again
+        for (uint32_t k = w; k < K; k += NW) {
+            const bool hitk = ok && ((s_kept[k] >> lane) & 1ull);
+            c_hit += (unsigned)__popcll(__ballot(hitk));
+            if (hitk && nbp[k].order > F.order) nbp[k].mask[s_hit[k * 64 + lane]] = 255;
+        }
+        // one wave: weighted fusion in neighbour order (:157-165), voxel key, record
         if (w == p3) {
-            bool ok = act;
-            unsigned n_obs = 0, n_close = 0;
             double wx = 0, wy = 0, wz = 0, total = 0;
-            for (uint32_t k = 0; k < K; k++) {                           // neighbour order, :160-163
+            for (uint32_t k = 0; k < K; k++) {
                 if ((s_kept[k] >> lane) & 1ull) {
-                    n_obs++;
-                    n_close += (unsigned)((s_close[k] >> lane) & 1ull);
                     const double *o = s_obs + (size_t)k * 256 + lane;
                     wx = wx + o[0];
                     wy = wy + o[64];
@@ -436,19 +473,9 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
                     total = total + o[192];
                 }
             }
-            if (n_obs < 1) ok = false;                                       // :218
-            if ((double)n_close < (double)n_obs * P.close_frac) ok = false;  // :229
-            unsigned c_hit = 0;
             unsigned long long key = 0, tag = kEmpty;
             double fx = 0, fy = 0, fz = 0;
             if (ok) {
-                for (uint32_t k = 0; k < K; k++) {                           // :152-154
-                    if ((s_kept[k] >> lane) & 1ull) {
-                        c_hit++;
-                        // masks of already-processed keyframes are never read again
-                        if (nbp[k].order > F.order) nbp[k].mask[s_hit[k * 64 + lane]] = 255;
-                    }
-                }
                 fx = wx / total; fy = wy / total; fz = wz / total;           // :164
                 unsigned long long c0_, c1_, c2_;
                 const int fits = (int)axis_code(voxel_index(fx, P.voxel_size), c0_) &
@@ -461,10 +488,11 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
                     atomicOr(&a.stat[blockIdx.x % kStatShards].err, kErrKeyRange);
                 }
             }
+            base_r = __shfl(base_r, 0);
             if (act) {
-                const unsigned long long rel = *s_base + c0 + lane;
+                const unsigned long long rel = base_r + lane;
                 if (rel < a.list.shard_cap) {
-                    const unsigned long long idx = (unsigned long long)shard * a.list.shard_cap + rel;
+                    const unsigned long long idx = (unsigned long long)(c % kListShards) * a.list.shard_cap + rel;
                     a.list.tag[idx] = tag;
                     if (tag != kEmpty) {
                         a.list.key[idx] = key;
@@ -477,21 +505,14 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void fuse_frame_kernel(
                     atomicOr(&a.stat[blockIdx.x % kStatShards].err, kErrListFull);
                 }
             }
-            c_hit = wave_sum(c_hit);
-            if (lane == 0 && c_hit) atomicAdd(&s_cnt[1], c_hit);
-            if (c0 == 0) SFM_STAMP(5);
         }
-        __syncthreads();  // s_obs/s_kept are reused by the next chunk; s_cnt complete at the end
+        if (c + gridDim.x < total_chunks) __syncthreads();  // LDS is reused by the next chunk
     }
-    if (w == 0 && lane == 0) {
-        StatShard *st = &a.stat[blockIdx.x % kStatShards];
-        if (s_cnt[0]) atomicAdd(&st->n_gather, (unsigned long long)s_cnt[0]);
-        if (s_cnt[1]) atomicAdd(&st->n_hit, (unsigned long long)s_cnt[1]);
+    if (lane == 0 && (c_gather | c_hit)) {
+        StatShard *st = &a.stat[(blockIdx.x * NW + w) % kStatShards];
+        if (c_gather) atomicAdd(&st->n_gather, (unsigned long long)c_gather);
+        if (c_hit) atomicAdd(&st->n_hit, (unsigned long long)c_hit);
     }
-    SFM_STAMP(6);
-#ifdef SFM_STAMPS
-    if (a.stamps && w == 0 && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] = n2;
-#endif
 }
 
 // ---- voxel table: first-wins filter for a group of keyframes ------------------------------
@@ -504,6 +525,7 @@ struct TableArgs {
     Counters *ctr;
     unsigned long long *frame_before;  // [n_frames] "Points before voxel filter" (:118)
     unsigned long long *frame_after;   // [n_frames] "Points after voxel filter"  (:120)
+    unsigned long long *cand;          // [list capacity] list indices that may still win
     uint32_t f0, f1;                   // keyframes [f0, f1), f1 - f0 <= kGroup (local indices)
     uint32_t group;
 };
@@ -528,44 +550,70 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
     const unsigned long long base = (unsigned long long)shard * a.list.shard_cap;
     const unsigned long long want_hi = (unsigned long long)a.group + 1ull;
     unsigned claims = 0, maxprobe = 0;
-    for (unsigned long long i = begin + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < end;
-         i += (unsigned long long)gridDim.x * blockDim.x) {
-        const unsigned long long tag = a.list.tag[base + i];
-        if (tag == kEmpty) continue;
-        const unsigned long long key = a.list.key[base + i];
-        const uint32_t fr = (uint32_t)(tag >> 32) - a.f0;
-        atomicAdd(&s_before[fr], 1u);
-        uint64_t h = mix64(key) & a.table_mask;
-        unsigned probes = 0;
-        bool found = false;
-        for (;;) {
-            unsigned long long cur = a.table[h].key;
-            if (cur == kEmpty) {
-                cur = atomicCAS(&a.table[h].key, kEmpty, key);
-                if (cur == kEmpty) { claims++; cur = key; }
+    __shared__ unsigned int s_ncand;
+    __shared__ unsigned long long s_cbase;
+    if (threadIdx.x == 0) s_ncand = 0;
+    const unsigned lane = lane_id();
+    // block-uniform trip count: the candidate append below synchronises the workgroup
+    for (unsigned long long i0 = begin + (unsigned long long)blockIdx.x * blockDim.x; i0 < end;
+         i0 += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long i = i0 + threadIdx.x;
+        const unsigned long long tag = i < end ? a.list.tag[base + i] : kEmpty;
+        bool lower = false;
+        if (tag != kEmpty) {
+            const unsigned long long key = a.list.key[base + i];
+            const uint32_t fr = (uint32_t)(tag >> 32) - a.f0;
+            atomicAdd(&s_before[fr], 1u);
+            uint64_t h = mix64(key) & a.table_mask;
+            unsigned probes = 0;
+            bool found = false;
+            for (;;) {
+                unsigned long long cur = a.table[h].key;
+                if (cur == kEmpty) {
+                    cur = atomicCAS(&a.table[h].key, kEmpty, key);
+                    if (cur == kEmpty) { claims++; cur = key; }
+                }
+                if (cur == key) { found = true; break; }
+                h = (h + 1) & a.table_mask;
+                if (++probes > 4096u || probes > a.table_mask) break;
             }
-            if (cur == key) { found = true; break; }
-            h = (h + 1) & a.table_mask;
-            if (++probes > 4096u || probes > a.table_mask) break;
+            if (!found) {
+                s_err = kErrTableFull;
+            } else {
+                if (probes > maxprobe) maxprobe = probes;
+                const unsigned long long seen = a.table[h].tag;
+                unsigned long long prev_tag = seen;
+                if (seen > tag) prev_tag = atomicMin(&a.table[h].tag, tag);
+                // Only an entry that was its voxel's smallest tag at this moment can still win:
+                // it goes on the candidate list that finalize_kernel walks.
+                lower = prev_tag > tag;
+                const unsigned long long bit = 1ull << fr;
+                unsigned long long old = a.mark[h];
+                for (;;) {
+                    const bool same = (old >> 32) == want_hi;
+                    if (same && (old & bit)) break;
+                    const unsigned long long neu = same ? (old | bit) : ((want_hi << 32) | bit);
+                    const unsigned long long prev = atomicCAS(&a.mark[h], old, neu);
+                    if (prev == old) { atomicAdd(&s_after[fr], 1u); break; }
+                    old = prev;
+                }
+            }
         }
-        if (!found) { s_err = kErrTableFull; continue; }
-        if (probes > maxprobe) maxprobe = probes;
-        // An entry that is not the smallest tag of its voxel at this moment can never win:
-        // drop it from the list so finalize_kernel does not probe for it again.
-        const unsigned long long seen = a.table[h].tag;
-        unsigned long long prev_tag = seen;
-        if (seen > tag) prev_tag = atomicMin(&a.table[h].tag, tag);
-        if (prev_tag < tag) a.list.tag[base + i] = kEmpty;
-        const unsigned long long bit = 1ull << fr;
-        unsigned long long old = a.mark[h];
-        for (;;) {
-            const bool same = (old >> 32) == want_hi;
-            if (same && (old & bit)) break;
-            const unsigned long long neu = same ? (old | bit) : ((want_hi << 32) | bit);
-            const unsigned long long prev = atomicCAS(&a.mark[h], old, neu);
-            if (prev == old) { atomicAdd(&s_after[fr], 1u); break; }
-            old = prev;
+        // candidate append: wave ballot -> one LDS add per wave -> one global add per workgroup
+        const unsigned long long m = __ballot(lower);
+        unsigned wbase = 0;
+        if (m != 0) {
+            const int leader = __ffsll((long long)m) - 1;
+            if ((int)lane == leader) wbase = atomicAdd(&s_ncand, (unsigned)__popcll(m));
+            wbase = __shfl(wbase, leader);
         }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_cbase = s_ncand ? atomicAdd(&a.ctr->cand_count, (unsigned long long)s_ncand) : 0ull;
+            s_ncand = 0;
+        }
+        __syncthreads();
+        if (lower) a.cand[s_cbase + wbase + (unsigned)__popcll(m & lanemask_lt())] = base + i;
     }
     if (claims) atomicAdd(&s_claims, claims);
     if (maxprobe) atomicMax(&s_maxprobe, maxprobe);
@@ -587,6 +635,7 @@ struct FinalizeArgs {
     const Slot *table;
     uint64_t table_mask;
     ListDev list;
+    const unsigned long long *cand;
     Counters *ctr;
     // output (SoA, device)
     double *out_xyz;
@@ -595,27 +644,25 @@ struct FinalizeArgs {
     unsigned long long *out_tag;
 };
 
-// A record is an output point iff its tag is the minimum recorded for its voxel.
+// A candidate is an output point iff its tag is (still) the minimum recorded for its voxel.
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
 {
     const unsigned lane = lane_id();
-    const uint32_t shard = blockIdx.y;
-    unsigned long long end = a.list.cursor[shard * 8];
-    if (end > a.list.shard_cap) end = a.list.shard_cap;
-    const unsigned long long base = (unsigned long long)shard * a.list.shard_cap;
+    const unsigned long long n = a.ctr->cand_count;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    const unsigned long long n_round = (end + 63) / 64 * 64;
+    const unsigned long long n_round = (n + 63) / 64 * 64;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         bool win = false;
-        unsigned long long key = 0, tag = kEmpty;
-        if (i < end) tag = a.list.tag[base + i];
-        if (tag != kEmpty) {
-            key = a.list.key[base + i];
+        unsigned long long key = 0, tag = 0, e = 0;
+        if (i < n) {
+            e = a.cand[i];
+            tag = a.list.tag[e];
+            key = a.list.key[e];
             uint64_t h = mix64(key) & a.table_mask;
             for (;;) {
                 const unsigned long long cur = a.table[h].key;
                 if (cur == key) { win = a.table[h].tag == tag; break; }
-                if (cur == kEmpty) break;  // cannot happen: every accepted key was inserted
+                if (cur == kEmpty) break;  // cannot happen: every candidate's key was inserted
                 h = (h + 1) & a.table_mask;
             }
         }
@@ -627,10 +674,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
             obase = __shfl(obase, leader);
             if (win) {
                 const unsigned long long o = obase + (unsigned)__popcll(m & lanemask_lt());
-                a.out_xyz[3 * o + 0] = a.list.xyz[3 * (base + i) + 0];
-                a.out_xyz[3 * o + 1] = a.list.xyz[3 * (base + i) + 1];
-                a.out_xyz[3 * o + 2] = a.list.xyz[3 * (base + i) + 2];
-                a.out_bgr[o] = a.list.bgr[base + i];
+                a.out_xyz[3 * o + 0] = a.list.xyz[3 * e + 0];
+                a.out_xyz[3 * o + 1] = a.list.xyz[3 * e + 1];
+                a.out_xyz[3 * o + 2] = a.list.xyz[3 * e + 2];
+                a.out_bgr[o] = a.list.bgr[e];
                 a.out_key[o] = key;
                 a.out_tag[o] = tag;
             }
