@@ -71,11 +71,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # SFM_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo -- a functional rehearsal of the N>1
+    # path on a one-GPU box (RCCL refuses two ranks on one device); never a measurement
+    rehearsal = os.environ.get("SFM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from sfm_amd import fusion, synth
 
@@ -167,7 +175,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
         "config": {"workload": args.workload, "keyframes_per_gpu": n_kf, "width": W, "height": H,
                    "voxel_size_raw_units": voxel, "T_dist_raw_units": t_dist,
                    "depth_unit": "mm", "neighbours": "temporal +-4",

@@ -78,13 +78,26 @@ class VoxelExchange:
         self.ctx.export_records(send.data_ptr(), n_local * RECORD_BYTES)
         send_counts = torch.tensor(counts, dtype=torch.int64, device=self.device)
         recv_counts = torch.empty_like(send_counts)
+        # gloo has no all-to-all on device tensors: stage through the host there (CPU tests and
+        # the single-GPU rehearsal of the N>1 path); RCCL ("nccl") moves device memory directly
+        staged = send.is_cuda and dist.get_backend(self.group) == "gloo"
+        if staged:
+            send_counts = send_counts.cpu()
+            recv_counts = recv_counts.cpu()
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         rc = [int(x) for x in recv_counts.tolist()]
         n_recv = sum(rc)
         recv = torch.empty(max(n_recv, 1) * RECORD_BYTES, dtype=torch.uint8, device=self.device)
-        dist.all_to_all_single(recv[: n_recv * RECORD_BYTES], send[: n_local * RECORD_BYTES],
-                               [r * RECORD_BYTES for r in rc], [c * RECORD_BYTES for c in counts],
-                               group=self.group)
+        in_splits = [c * RECORD_BYTES for c in counts]
+        out_splits = [r * RECORD_BYTES for r in rc]
+        if staged:
+            h_recv = torch.empty(n_recv * RECORD_BYTES, dtype=torch.uint8)
+            dist.all_to_all_single(h_recv, send[: n_local * RECORD_BYTES].cpu(), out_splits, in_splits,
+                                   group=self.group)
+            recv[: n_recv * RECORD_BYTES].copy_(h_recv)
+        else:
+            dist.all_to_all_single(recv[: n_recv * RECORD_BYTES], send[: n_local * RECORD_BYTES],
+                                   out_splits, in_splits, group=self.group)
         if recv.is_cuda:
             torch.cuda.current_stream(recv.device).synchronize()
         self.ctx.merge(recv.data_ptr(), n_recv)
