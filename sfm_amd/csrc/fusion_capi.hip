@@ -56,6 +56,10 @@ struct sfm_fusion_ctx {
     int device = 0;
     hipStream_t stream = nullptr;    // stream A
     hipStream_t stream_b = nullptr;  // stream B (table kernels)
+#if SFM_STAMPS
+    unsigned long long *stamp_ptr = nullptr;
+    size_t stamp_n = 0;
+#endif
     bool own_stream = false;
     std::vector<HostFrame> frames;
     bool layout_dirty = true;
@@ -82,6 +86,10 @@ struct sfm_fusion_ctx {
     hipEvent_t ev_init = nullptr, ev_b_done = nullptr;
     std::vector<hipEvent_t> gev;  // one per keyframe group
     uint32_t max_waves = 4;          // waves per observe workgroup (SFM_FUSE_WAVES overrides)
+    // table_group_kernel workgroups per list shard (SFM_TABLE_WGS overrides).  Deliberately small:
+    // the kernel is off the keyframe chain, and a chip-filling grid slows the chain kernels it
+    // overlaps by more than it gains (r01v6 sweep: 64 -> 14.7 ms, 16 -> 13.2 ms, 4 -> 13.9 ms per C2 run)
+    uint32_t table_wgs = 16;
     uint32_t waves_per_cu = 28;      // resident observe waves per CU (SFM_FUSE_RESIDENT overrides)
     bool profile = false;         // per-launch start/stop events on the frame kernels
     std::vector<hipEvent_t> kev;  // 2 per keyframe when profiling
@@ -383,6 +391,18 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
             const uint32_t resident = (uint32_t)c->n_cu * std::max<uint32_t>(1, c->waves_per_cu / nw);
             const uint32_t wgs = (uint32_t)std::min<uint64_t>((px + kWave - 1) / kWave, resident);
             const size_t lds = fuse_lds_bytes(f.n_filtered);
+#if SFM_STAMPS
+            a.stamps = nullptr;
+            static unsigned long long *d_stamps = nullptr;
+            const char *sf = std::getenv("SFM_STAMP_FRAME");
+            if (sf && (size_t)std::atoi(sf) == i) {
+                if (!d_stamps) (void)hipMalloc(&d_stamps, (size_t)8192 * 8 * 8 * 8);
+                (void)hipMemsetAsync(d_stamps, 0, (size_t)8192 * 8 * 8 * 8, sa);
+                a.stamps = d_stamps;
+                c->stamp_ptr = d_stamps;
+                c->stamp_n = (size_t)wgs * nw * 8;
+            }
+#endif
             if (c->profile) {
                 hipExtLaunchKernelGGL(scan_frame_kernel, dim3(tiles), dim3(kWave), 0, sa, c->kev[4 * i],
                                       c->kev[4 * i + 1], 0, sc);
@@ -403,10 +423,20 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
             t.f0 = (uint32_t)(g * kGroup);
             t.f1 = (uint32_t)(i + 1);
             t.group = (uint32_t)g;
-            hipLaunchKernelGGL(table_group_kernel, dim3(64, kListShards), dim3(256), 0, sb, t);
+            hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, kListShards), dim3(256), 0, sb, t);
         }
     }
     HIP_TRY(c, hipGetLastError());
+#if SFM_STAMPS
+    if (c->stamp_ptr) {
+        std::vector<unsigned long long> h(c->stamp_n);
+        (void)hipStreamSynchronize(sa);
+        (void)hipMemcpy(h.data(), c->stamp_ptr, c->stamp_n * 8, hipMemcpyDeviceToHost);
+        if (const char *o = std::getenv("SFM_STAMP_OUT")) {
+            if (FILE *fp = std::fopen(o, "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
+        }
+    }
+#endif
     HIP_TRY(c, hipEventRecord(c->ev[2], sa));
     HIP_TRY(c, hipEventRecord(c->ev_b_done, sb));
     HIP_TRY(c, hipStreamWaitEvent(sa, c->ev_b_done, 0));
@@ -495,6 +525,10 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
     }
     std::memset(&c->stats, 0, sizeof c->stats);
     bool ok = hipSetDevice(device) == hipSuccess;
+    if (const char *e = std::getenv("SFM_TABLE_WGS")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 1024) c->table_wgs = (uint32_t)v;
+    }
     if (ok && stream) {
         c->stream = (hipStream_t)stream;
     } else if (ok) {

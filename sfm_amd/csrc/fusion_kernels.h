@@ -14,8 +14,16 @@
 //                       second stream, off the keyframe chain.
 //   finalize_kernel     gathers the winners into the output cloud.
 #pragma once
-#ifndef SFM_ABLATE_EXIT
-#define SFM_ABLATE_EXIT 0
+#ifndef SFM_OBSERVE_WAVES_PER_EU
+#define SFM_OBSERVE_WAVES_PER_EU 6
+#endif
+#if SFM_OBSERVE_WAVES_PER_EU > 0
+#define SFM_OBSERVE_OCC __attribute__((amdgpu_waves_per_eu(SFM_OBSERVE_WAVES_PER_EU, 8)))
+#else
+#define SFM_OBSERVE_OCC
+#endif
+#ifndef SFM_STAMPS
+#define SFM_STAMPS 0  // diagnostic build only (tools_stamps.sh): per-wave phase timestamps of one launch
 #endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -335,12 +343,84 @@ struct FuseArgs {
     ListDev list;
     StatShard *stat;           // [kStatShards]
     DevParams P;
+#if SFM_STAMPS
+    unsigned long long *stamps;  // [gridDim.x * waves][8] 100-MHz timestamps, or nullptr
+#endif
 };
+
+#if SFM_STAMPS
+#define SFM_STAMP(i)                                                                               \
+    do {                                                                                           \
+        if (a.stamps && lane == 0 && first_chunk)                                                  \
+            a.stamps[((size_t)blockIdx.x * NW + w) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();   \
+    } while (0)
+#define SFM_STAMP_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define SFM_STAMP(i) do {} while (0)
+#define SFM_STAMP_WAIT() do {} while (0)
+#endif
+
+// One re-observation, split at its two memory round trips so that observe_frame_kernel can keep
+// two neighbours in flight per wave.
+struct ObsProj {
+    uint32_t npix;  // floored projection as a pixel index (0 when not visible)
+    int ix, iy;
+    bool vis;
+};
+
+// KeyFrame::point_in_frame, keyframe.cpp:275-294 / pinhole.cpp:32-45
+__device__ __forceinline__ ObsProj obs_project(const FrameDev &L, double pwx, double pwy, double pwz, bool on)
+{
+    const double cx_ = row_apply(L.Tkw, 0, pwx, pwy, pwz);
+    const double cy_ = row_apply(L.Tkw, 1, pwx, pwy, pwz);
+    const double cz_ = row_apply(L.Tkw, 2, pwx, pwy, pwz);
+    const double px = (cx_ / cz_) * L.K[0] + L.K[2];
+    const double py = (cy_ / cz_) * L.K[1] + L.K[3];
+    ObsProj r;
+    // NaN projections are "not visible" (UB in the reference): hence the >= 0 form
+    r.vis = on && (px >= 0) && (px < (double)L.W) && (py >= 0) && (py < (double)L.H) && !(cz_ < 0);
+    r.ix = r.vis ? (int)floor(px) : 0;
+    r.iy = r.vis ? (int)floor(py) : 0;
+    r.npix = (uint32_t)r.iy * (uint32_t)L.W + (uint32_t)r.ix;
+    return r;
+}
+
+// dense_reconstruction.cpp:193-216 after the gathers: back-projection of the neighbour's depth,
+// its covariance trace (bit-equal to cov_trace_tab), the kept (:204) / close (:224) tests, and the
+// weighted observation (:161-162) left in LDS for the fusing wave.
+__device__ __forceinline__ void obs_finish(const FrameDev &L, const DevParams &P, const ObsProj &p, uint32_t draw,
+                                           double x, double y, double2 e01, double2 e23, double pwx, double pwy,
+                                           double pwz, double *o, uint32_t *hit, bool &kept, bool &close)
+{
+    const double d = (double)draw;
+    const double qcx = x * d, qcy = y * d, qcz = d;
+    const double qx = row_apply(L.Twk, 0, qcx, qcy, qcz);
+    const double qy = row_apply(L.Twk, 1, qcx, qcy, qcz);
+    const double qz = row_apply(L.Twk, 2, qcx, qcy, qcz);
+    const double dd = e23.x;
+    const double J02 = ((double)(-p.ix) * P.base_line) / dd;
+    const double J12 = ((double)(-p.iy) * P.base_line) / dd;
+    const double P00 = e01.x + (J02 * P.S2) * J02;
+    const double P11 = e01.y + (J12 * P.S2) * J12;
+    const double wgt = P00 + (P11 + e23.y);                              // :202
+    kept = p.vis && (wgt < P.T_cov);                                     // :204
+    const double dx = qx - pwx, dy = qy - pwy, dz = qz - pwz;
+    const double s = (dx * dx + dy * dy) + dz * dz;                      // norm(): (e0+e1)+e2
+    close = kept && (s < P.tau_dist2);                                   // :224
+    if (kept) {
+        const double inv = 1.0 / wgt;                                    // :161-162
+        o[0] = qx * inv;
+        o[64] = qy * inv;
+        o[128] = qz * inv;
+        o[192] = inv;
+        *hit = p.npix;
+    }
+}
 
 // geometric_check + the tail of process_pixel (dense_reconstruction.cpp:146-175, :177-234).
 // nbp = this keyframe's filtered neighbours, one FrameDev copy each, in neighbour order
 // (never written by any kernel: __restrict__ keeps the reads on the scalar path).
-__global__ __launch_bounds__(kMaxWaves * kWave) void observe_frame_kernel(
+__global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_frame_kernel(
     const FrameDev *__restrict__ nbp, FuseArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -351,101 +431,93 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void observe_frame_kernel(
     const FrameDev &F = a.F;
     const DevParams &P = a.P;
     const uint32_t K = F.nbr_count;
+#if SFM_STAMPS
+    bool first_chunk = true;
+#endif
+    SFM_STAMP(0);
     double *s_obs = reinterpret_cast<double *>(smem);
     uint32_t *s_hit = reinterpret_cast<uint32_t *>(s_obs + (size_t)K * 256);
     unsigned long long *s_kept = reinterpret_cast<unsigned long long *>(s_hit + (size_t)K * 64);
     unsigned long long *s_close = s_kept + K;
 
-    // chunks of 64 survivors, shard after shard
-    uint32_t cnt[kQueueShards];
-    uint32_t total_chunks = 0;
-#pragma unroll
-    for (int s = 0; s < kQueueShards; s++) {
-        cnt[s] = a.q.count[s * 16];
-        total_chunks += (cnt[s] + kWave - 1) / kWave;
-    }
+    // Chunks of 64 survivors.  Chunk c is the (c / 16)-th chunk of queue shard c % 16: where its
+    // data lives does not depend on the shard counts, so the loads go out together with the
+    // count reads instead of one memory round trip behind them.
     const size_t plane = (size_t)kQueueShards * a.q.shard_cap;
     unsigned c_gather = 0, c_hit = 0;
-    for (uint32_t c = blockIdx.x; c < total_chunks; c += gridDim.x) {
-        uint32_t shard = 0, j = c, n_in = 0;
+    uint32_t max_cnt = 0;
 #pragma unroll
-        for (int s = 0; s < kQueueShards; s++) {
-            const uint32_t nc = (cnt[s] + kWave - 1) / kWave;
-            if (n_in == 0) {
-                if (j < nc) { shard = s; n_in = min(cnt[s] - j * kWave, (uint32_t)kWave); }
-                else j -= nc;
-            }
-        }
+    for (int s = 0; s < kQueueShards; s++) max_cnt = max(max_cnt, a.q.count[s * 16]);
+    const uint32_t total_chunks = ((max_cnt + kWave - 1) / kWave) * kQueueShards;
+    SFM_STAMP(1);
+    for (uint32_t c = blockIdx.x; c < total_chunks; c += gridDim.x) {
+        const uint32_t shard = c % kQueueShards, j = c / kQueueShards;
+        const uint32_t cnt_s = a.q.count[shard * 16];
+        const uint32_t qo = min(j * kWave + lane, a.q.shard_cap - 1);  // in bounds whatever cnt_s is
+        const size_t qi = (size_t)shard * a.q.shard_cap + qo;
+        const double pwx = a.q.pw[qi];
+        const double pwy = a.q.pw[plane + qi];
+        const double pwz = a.q.pw[2 * plane + qi];
+        const uint32_t pix_q = a.q.pix[qi];
+        if (j * kWave >= cnt_s) continue;  // workgroup-uniform: no chunk here (shards differ in length)
+        const uint32_t n_in = min(cnt_s - j * kWave, (uint32_t)kWave);
         const bool act = lane < n_in;
         const unsigned p3 = c % NW;  // the wave that finishes this chunk (spreads over the SIMDs)
-        const size_t qi = (size_t)shard * a.q.shard_cap + (size_t)j * kWave + lane;
-        double pwx = 0, pwy = 0, pwz = 0;
         uint32_t pix = 0, col = 0;
         unsigned long long base_r = 0;
-        if (act) {
-            pwx = a.q.pw[qi];
-            pwy = a.q.pw[plane + qi];
-            pwz = a.q.pw[2 * plane + qi];
-        }
         if (w == p3) {
             // list space for the chunk: issued now, consumed after the neighbour work
             if (lane == 0) base_r = atomicAdd(&a.list.cursor[(c % kListShards) * 8], (unsigned long long)n_in);
             if (act) {                                                   // :170, features.cpp:76-80
-                pix = a.q.pix[qi];
+                pix = pix_q;
                 const uint8_t *cp = F.bgr + 3ull * pix;
                 col = (uint32_t)cp[0] | ((uint32_t)cp[1] << 8) | ((uint32_t)cp[2] << 16);
             }
         }
-        // wave w re-observes the chunk in neighbours w, w+NW, ...  (:187-216)
-        for (uint32_t k = w; k < K; k += NW) {
-            const FrameDev &L = nbp[k];
-            bool kept = false, close = false, vis = false;
-            if (act) {
-                // KeyFrame::point_in_frame, keyframe.cpp:275-294 / pinhole.cpp:32-45
-                const double cx_ = row_apply(L.Tkw, 0, pwx, pwy, pwz);
-                const double cy_ = row_apply(L.Tkw, 1, pwx, pwy, pwz);
-                const double cz_ = row_apply(L.Tkw, 2, pwx, pwy, pwz);
-                const double px = (cx_ / cz_) * L.K[0] + L.K[2];
-                const double py = (cy_ / cz_) * L.K[1] + L.K[3];
-                // NaN projections are "not visible" (UB in the reference): hence the >= 0 form
-                vis = (px >= 0) && (px < (double)L.W) && (py >= 0) && (py < (double)L.H) && !(cz_ < 0);
-                if (vis) {
-                    const int ix = (int)floor(px);
-                    const int iy = (int)floor(py);
-                    const uint32_t npix = (uint32_t)iy * (uint32_t)L.W + (uint32_t)ix;
-                    const uint32_t draw = L.depth[npix];                 // :193 (no d>0 test)
-                    const double d = (double)draw;
-                    const double x = L.xtab[ix];
-                    const double y = L.ytab[iy];
-                    const double qcx = x * d, qcy = y * d, qcz = d;
-                    const double qx = row_apply(L.Twk, 0, qcx, qcy, qcz);
-                    const double qy = row_apply(L.Twk, 1, qcx, qcy, qcz);
-                    const double qz = row_apply(L.Twk, 2, qcx, qcy, qcz);
-                    const double wgt = cov_trace_tab(P, ix, iy, L.ctab + 4 * (size_t)draw);  // :202
-                    if (wgt < P.T_cov) {                                 // :204
-                        kept = true;
-                        const double dx = qx - pwx, dy = qy - pwy, dz = qz - pwz;
-                        const double s = (dx * dx + dy * dy) + dz * dz;  // norm(): (e0+e1)+e2
-                        close = s < P.tau_dist2;                         // :224
-                        const double inv = 1.0 / wgt;                    // :161-162
-                        double *o = s_obs + (size_t)k * 256 + lane;
-                        o[0] = qx * inv;
-                        o[64] = qy * inv;
-                        o[128] = qz * inv;
-                        o[192] = inv;
-                        s_hit[k * 64 + lane] = npix;
-                    }
+        SFM_STAMP_WAIT();
+        SFM_STAMP(2);
+        // wave w re-observes the chunk in neighbours w, w+NW, ...  (:187-216), two at a time:
+        // both projections, then both depth gathers, then both table reads are in flight
+        // together (branch-free; a lane without a visible projection reads element 0)
+        for (uint32_t k0 = w; k0 < K; k0 += 2 * NW) {
+            const uint32_t k1 = k0 + NW;
+            const bool has1 = k1 < K;  // wave-uniform
+            const FrameDev &L0 = nbp[k0];
+            const FrameDev &L1 = nbp[has1 ? k1 : k0];
+            ObsProj p0 = obs_project(L0, pwx, pwy, pwz, act);
+            ObsProj p1 = obs_project(L1, pwx, pwy, pwz, act && has1);
+            const uint32_t draw0 = L0.depth[p0.npix];                    // :193 (no d>0 test)
+            const uint32_t draw1 = L1.depth[p1.npix];
+            const double x0 = L0.xtab[p0.ix], y0 = L0.ytab[p0.iy];
+            const double x1 = L1.xtab[p1.ix], y1 = L1.ytab[p1.iy];
+            const double *e0 = L0.ctab + 4 * (size_t)draw0;
+            const double *e1 = L1.ctab + 4 * (size_t)draw1;
+            const double2 e0a = *reinterpret_cast<const double2 *>(e0);
+            const double2 e0b = *reinterpret_cast<const double2 *>(e0 + 2);
+            const double2 e1a = *reinterpret_cast<const double2 *>(e1);
+            const double2 e1b = *reinterpret_cast<const double2 *>(e1 + 2);
+            bool kept0, close0, kept1, close1;
+            obs_finish(L0, P, p0, draw0, x0, y0, e0a, e0b, pwx, pwy, pwz, s_obs + (size_t)k0 * 256 + lane,
+                       s_hit + k0 * 64 + lane, kept0, close0);
+            obs_finish(L1, P, p1, draw1, x1, y1, e1a, e1b, pwx, pwy, pwz,
+                       s_obs + (size_t)(has1 ? k1 : k0) * 256 + lane, s_hit + (has1 ? k1 : k0) * 64 + lane,
+                       kept1, close1);
+            const unsigned long long mk0 = __ballot(kept0), mc0 = __ballot(close0);
+            const unsigned long long mk1 = __ballot(kept1), mc1 = __ballot(close1);
+            c_gather += (unsigned)__popcll(__ballot(p0.vis)) + (unsigned)__popcll(__ballot(p1.vis));
+            if (lane == 0) {
+                s_kept[k0] = mk0;
+                s_close[k0] = mc0;
+                if (has1) {
+                    s_kept[k1] = mk1;
+                    s_close[k1] = mc1;
                 }
             }
-            const unsigned long long mk_ = __ballot(kept);
-            const unsigned long long mc_ = __ballot(close);
-            c_gather += (unsigned)__popcll(__ballot(vis));
-            if (lane == 0) {
-                s_kept[k] = mk_;
-                s_close[k] = mc_;
-            }
         }
+        SFM_STAMP_WAIT();
+        SFM_STAMP(3);
         __syncthreads();
+        SFM_STAMP(4);
         // every wave: the decision (:218, :229) from the ballots ...
         unsigned n_obs = 0, n_close = 0;
         for (uint32_t k = 0; k < K; k++) {
@@ -461,16 +533,30 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void observe_frame_kernel(
             c_hit += (unsigned)__popcll(__ballot(hitk));
             if (hitk && nbp[k].order > F.order) nbp[k].mask[s_hit[k * 64 + lane]] = 255;
         }
+        SFM_STAMP(5);
         // one wave: weighted fusion in neighbour order (:157-165), voxel key, record
         if (w == p3) {
+            // the sums run in neighbour order; the LDS reads do not depend on them and are issued
+            // kFuseBatch neighbours at a time (a slot without a kept observation holds stale bits that
+            // the select below never lets into the sums)
             double wx = 0, wy = 0, wz = 0, total = 0;
-            for (uint32_t k = 0; k < K; k++) {
-                if ((s_kept[k] >> lane) & 1ull) {
+            constexpr int kFuseBatch = 2;
+            for (uint32_t kb = 0; kb < K; kb += kFuseBatch) {
+                double ox[kFuseBatch], oy[kFuseBatch], oz[kFuseBatch], ow[kFuseBatch];
+                bool on[kFuseBatch];
+#pragma unroll
+                for (int i = 0; i < kFuseBatch; i++) {
+                    const uint32_t k = min(kb + i, K - 1);
                     const double *o = s_obs + (size_t)k * 256 + lane;
-                    wx = wx + o[0];
-                    wy = wy + o[64];
-                    wz = wz + o[128];
-                    total = total + o[192];
+                    ox[i] = o[0]; oy[i] = o[64]; oz[i] = o[128]; ow[i] = o[192];
+                    on[i] = (kb + i < K) && ((s_kept[k] >> lane) & 1ull);
+                }
+#pragma unroll
+                for (int i = 0; i < kFuseBatch; i++) {
+                    wx = on[i] ? wx + ox[i] : wx;
+                    wy = on[i] ? wy + oy[i] : wy;
+                    wz = on[i] ? wz + oz[i] : wz;
+                    total = on[i] ? total + ow[i] : total;
                 }
             }
             unsigned long long key = 0, tag = kEmpty;
@@ -506,6 +592,11 @@ __global__ __launch_bounds__(kMaxWaves * kWave) void observe_frame_kernel(
                 }
             }
         }
+        SFM_STAMP_WAIT();
+        SFM_STAMP(6);
+#if SFM_STAMPS
+        first_chunk = false;
+#endif
         if (c + gridDim.x < total_chunks) __syncthreads();  // LDS is reused by the next chunk
     }
     if (lane == 0 && (c_gather | c_hit)) {
