@@ -39,8 +39,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def observe_bytes(st):
-    """Algorithmic bytes of observe_frame_kernel, the dominant kernel (SURVEY.md 8d terms that
-    it moves): 2 B per neighbour depth gather, 3 B colour and one 16-B slot read+write (its
+    """Algorithmic bytes of observe_frame_kernel (SURVEY.md 8d terms that it moves; with
+    scan_bytes() the terms of fuse_chain_kernel, which does both jobs): 2 B per neighbour depth gather, 3 B colour and one 16-B slot read+write (its
     record hand-off to the voxel table) per accepted pixel, 1 B per mask store."""
     return 2 * st["n_gather"] + 3 * st["n_acc"] + st["n_hit"] + 32 * st["n_acc"]
 
@@ -140,15 +140,20 @@ def main():
         dist.all_reduce(t)
         n_points = int(t.item())
 
-    # roofline of the dominant kernel (observe_frame_kernel): one extra, untimed, run with
-    # per-dispatch start/stop events on the library's stream
+    # roofline of the dominant kernel: one extra, untimed, run with start/stop events around
+    # every dispatch of it on the library's stream
     ctx.set_profiling(True)
     ctx.run()
     pst = ctx.stats()
     ctx.set_profiling(False)
     launches = max(1, pst["fuse_kernel_launches"])
     avg_launch_s = pst["fuse_kernel_sum_ms"] * 1e-3 / launches
-    bytes_per_launch = observe_bytes(pst) / launches
+    # the persistent fuse_chain_kernel does the work of both per-keyframe kernels for a group of
+    # 32 keyframes per launch; on the fallback path the dominant kernel is observe_frame_kernel
+    chain = bool(pst["fused_chain"])
+    kernel_name = "fuse_chain_kernel" if chain else "observe_frame_kernel"
+    kernel_bytes = observe_bytes(pst) + (scan_bytes(pst) if chain else 0)
+    bytes_per_launch = kernel_bytes / launches
     scan_avg_s = pst["scan_kernel_sum_ms"] * 1e-3 / launches
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     traffic = None
@@ -156,7 +161,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload and not args.frames:
+            if tj.get("workload") == args.workload and not args.frames and tj.get("kernel") == kernel_name:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -185,7 +190,8 @@ def main():
         "device_ms_per_step_rank0": st["last_run_ms"],
         "roofline": {
             "bound": "hbm",
-            "kernel": "observe_frame_kernel",
+            "kernel": kernel_name,
+            "keyframes_per_launch": n_kf / launches,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -194,8 +200,9 @@ def main():
             "bytes_per_launch": bytes_per_launch,
             "avg_launch_us": avg_launch_s * 1e6,
             "launches_per_step": launches,
-            "scan_kernel": {"avg_launch_us": scan_avg_s * 1e6, "bytes_per_launch": scan_bytes(pst) / launches,
-                            "achieved": scan_bytes(pst) / launches / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0},
+            "scan_kernel": None if chain else {
+                "avg_launch_us": scan_avg_s * 1e6, "bytes_per_launch": scan_bytes(pst) / launches,
+                "achieved": scan_bytes(pst) / launches / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0},
             "whole_step_frac": total_bytes(st) / (st["last_run_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             if st["last_run_ms"] > 0 else None,
         },

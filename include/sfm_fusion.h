@@ -80,9 +80,11 @@ typedef struct sfm_fusion_stats {
     double frame_kernels_ms;/* device time between first and last per-frame kernel */
     /* filled when sfm_fusion_set_profiling(ctx,1): per-dispatch start/stop timestamps of the
      * per-keyframe kernel (same clock rocprofv3 --kernel-trace reads) */
-    uint64_t fuse_kernel_launches;   /* observe_frame_kernel dispatches (one per keyframe) */
+    uint64_t fuse_kernel_launches;   /* dispatches of the keyframe-chain kernel: fuse_chain_kernel (one per
+                                      * group of 32 keyframes) or observe_frame_kernel (one per keyframe) */
     double fuse_kernel_sum_ms;       /* sum of their durations */
-    double scan_kernel_sum_ms;       /* sum of the scan_frame_kernel durations */
+    double scan_kernel_sum_ms;       /* sum of the scan_frame_kernel durations (0 with fuse_chain_kernel) */
+    uint64_t fused_chain;            /* 1: the persistent fuse_chain_kernel ran; 0: the scan+observe pair */
 } sfm_fusion_stats;
 
 void sfm_fusion_default_params(sfm_fusion_params *p);

@@ -66,6 +66,16 @@ struct sfm_fusion_ctx {
 
     DevBuf<double> d_tables;         // x/y/covariance lookup tables
     DevBuf<FrameDev> d_nbrpack;      // per keyframe: a FrameDev copy of each filtered neighbour
+    DevBuf<FrameDev> d_frames;       // every keyframe (fuse_chain_kernel reads them on the device)
+    DevBuf<unsigned int> d_bar;      // device-wide barrier words of fuse_chain_kernel
+    // keyframe chain: 1 = one persistent fuse_chain_kernel per group of keyframes (default when the
+    // device can hold it), 0 = scan_frame_kernel + observe_frame_kernel per keyframe (SFM_FUSE_CHAIN)
+    bool chain = true;
+    bool chain_coop = true;          // cooperative launch (SFM_CHAIN_COOP=0: plain launch)
+    uint32_t chain_items = 0;        // (chunk, neighbour) LDS slots; 0 = chain kernel unusable here
+    size_t chain_lds = 0;
+    bool chain_ran = false;
+    uint32_t chain_fallbacks = 0;    // times a barrier timeout sent this ctx back to the kernel pair
     std::vector<FrameDev> h_frames;  // device-side description of every keyframe (host copy)
     DevBuf<uint8_t> d_masks;
     DevBuf<Slot> d_table;
@@ -206,6 +216,7 @@ int build_layout(sfm_fusion_ctx *c)
     for (auto &f : c->frames) c->total_px += (uint64_t)f.W * f.H;
     int rc;
     if ((rc = ensure(c, c->d_masks, total))) return rc;
+    if ((rc = ensure(c, c->d_bar, kBarBytes / sizeof(unsigned int)))) return rc;
     std::vector<FrameDev> &fd = c->h_frames;
     fd.assign(n, FrameDev());
     std::vector<uint32_t> nbr;
@@ -261,6 +272,15 @@ int build_layout(sfm_fusion_ctx *c)
         d.mask = c->d_masks.p + moff[i];
         d.xtab = c->d_tables.p + xo[i];
         d.ytab = c->d_tables.p + yo[i];
+        if ((uint64_t)f.W * f.H == 0) {
+            // an empty image is never visible and has no pixels, but the kernels' branch-free
+            // gathers read element 0 of whatever they are given: give them readable memory
+            d.depth = reinterpret_cast<const uint16_t *>(c->d_bar.p);
+            d.bgr = reinterpret_cast<const uint8_t *>(c->d_bar.p);
+            d.mask = reinterpret_cast<uint8_t *>(c->d_bar.p);
+            d.xtab = c->d_tables.p;
+            d.ytab = c->d_tables.p;
+        }
         d.ctab = c->d_tables.p + co[i];
         d.W = f.W;
         d.H = f.H;
@@ -280,6 +300,8 @@ int build_layout(sfm_fusion_ctx *c)
     std::vector<FrameDev> pack(nbr.size());
     for (size_t j = 0; j < nbr.size(); j++) pack[j] = fd[nbr[j]];
     if ((rc = ensure(c, c->d_nbrpack, pack.size()))) return rc;
+    if ((rc = ensure(c, c->d_frames, n))) return rc;
+    if (n) HIP_TRY(c, hipMemcpy(c->d_frames.p, fd.data(), n * sizeof(FrameDev), hipMemcpyHostToDevice));
     if ((rc = ensure(c, c->d_fbefore, n))) return rc;
     if ((rc = ensure(c, c->d_fafter, n))) return rc;
     if ((rc = ensure(c, c->d_group_end, (n + kGroup - 1) / kGroup * kListShards * 8))) return rc;
@@ -373,10 +395,62 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     t.cand = c->d_cand.p;
 
     HIP_TRY(c, hipEventRecord(c->ev[1], sa));
-    for (size_t i = 0; i < n; i++) {  // :48-52, strictly in order
-        const HostFrame &f = c->frames[i];
-        const uint64_t px = (uint64_t)f.W * f.H;
-        if (px) {
+    // the persistent chain kernel needs every keyframe's neighbour count to fit its LDS slots
+    bool use_chain = c->chain && c->chain_items > 0;
+    for (size_t i = 0; use_chain && i < n; i++)
+        if (c->frames[i].n_filtered > c->chain_items) use_chain = false;
+    c->chain_ran = use_chain;
+    for (size_t g = 0; g < n_groups; g++) {
+        const size_t g0 = g * kGroup, g1 = std::min(n, g0 + kGroup);
+        if (use_chain) {
+            // :48-52 for keyframes [g0, g1) in one launch; order is kept by the in-kernel barrier
+            ChainArgs ca;
+            ca.f0 = (uint32_t)g0;
+            ca.f1 = (uint32_t)g1;
+            ca.item_cap = c->chain_items;
+            ca.pad = 0;
+            ca.list = list;
+            ca.stat = dev_stat(c);
+            ca.bar = c->d_bar.p;
+            ca.P = a.P;
+            const FrameDev *fr = c->d_frames.p;
+            const FrameDev *np = c->d_nbrpack.p;
+#if SFM_STAMPS
+            ca.stamps = nullptr;
+            static unsigned long long *d_cstamps = nullptr;
+            const char *sg = std::getenv("SFM_STAMP_GROUP");
+            if (sg && (size_t)std::atoi(sg) == g) {
+                const size_t bytes = (size_t)kGroup * c->n_cu * 16 * 8 + (size_t)c->n_cu * 16 * 8 * 4 * 8;
+                if (!d_cstamps) (void)hipMalloc(&d_cstamps, bytes);
+                (void)hipMemsetAsync(d_cstamps, 0, bytes, sa);
+                ca.stamps = d_cstamps;
+                c->stamp_ptr = d_cstamps;
+                c->stamp_n = (size_t)kGroup * c->n_cu * 16 + (size_t)c->n_cu * 16 * 8 * 4;
+            }
+#endif
+            HIP_TRY(c, hipMemsetAsync(c->d_bar.p, 0, kBarBytes, sa));
+            if (c->profile) HIP_TRY(c, hipEventRecord(c->kev[4 * g], sa));
+            if (c->chain_coop) {
+                void *args[] = {(void *)&fr, (void *)&np, (void *)&ca};
+                if (hipLaunchCooperativeKernel((const void *)fuse_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), args,
+                                               (unsigned int)c->chain_lds, sa) != hipSuccess) {
+                    // the runtime refuses the grid (fewer CUs available than the device reports):
+                    // same outcome as a barrier timeout -- the caller reruns with the kernel pair
+                    (void)hipGetLastError();
+                    HIP_TRY(c, hipStreamSynchronize(sa));
+                    HIP_TRY(c, hipStreamSynchronize(sb));
+                    *err_bits = kErrBarrier;
+                    return SFM_OK;
+                }
+            } else {
+                hipLaunchKernelGGL(fuse_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa, fr, np, ca);
+            }
+            if (c->profile) HIP_TRY(c, hipEventRecord(c->kev[4 * g + 1], sa));
+        } else
+        for (size_t i = g0; i < g1; i++) {  // :48-52, strictly in order
+            const HostFrame &f = c->frames[i];
+            const uint64_t px = (uint64_t)f.W * f.H;
+            if (!px) continue;
             const uint32_t nw = std::min<uint32_t>(std::max<uint32_t>(f.n_filtered, 1), c->max_waves);
             q.count = c->d_qcount.p + i * kQueueShards * 16;
             sc.F = c->h_frames[i];
@@ -413,15 +487,14 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
                 hipLaunchKernelGGL(observe_frame_kernel, dim3(wgs), dim3(nw * kWave), lds, sa, nbp, a);
             }
         }
-        if (i % kGroup == kGroup - 1 || i + 1 == n) {
-            const size_t g = i / kGroup;
+        {
             // list boundaries of the group: snapshot of the append cursors, in stream order
             HIP_TRY(c, hipMemcpyAsync(c->d_group_end.p + g * kListShards * 8, dev_cursor(c),
                                       kListShards * 8 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, sa));
             HIP_TRY(c, hipEventRecord(c->gev[g], sa));
             HIP_TRY(c, hipStreamWaitEvent(sb, c->gev[g], 0));
-            t.f0 = (uint32_t)(g * kGroup);
-            t.f1 = (uint32_t)(i + 1);
+            t.f0 = (uint32_t)g0;
+            t.f1 = (uint32_t)g1;
             t.group = (uint32_t)g;
             hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, kListShards), dim3(256), 0, sb, t);
         }
@@ -525,6 +598,29 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
     }
     std::memset(&c->stats, 0, sizeof c->stats);
     bool ok = hipSetDevice(device) == hipSuccess;
+    if (ok && c->chain) {
+        // fuse_chain_kernel: as many (chunk, neighbour) LDS slots as one workgroup may allocate
+        int lds_max = 0, coop = 0;
+        if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) lds_max = 0;
+        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) != hipSuccess) coop = 0;
+        const size_t fixed = chain_lds_bytes(0);
+        // 4 KiB of every CU's LDS stay free: the table kernels of the previous group (512 B per
+        // workgroup) must be able to share the CUs, or each chain launch waits for them to drain
+        const size_t budget = lds_max > 4096 ? (size_t)lds_max - 4096 : 0;
+        uint32_t items = budget > fixed ? (uint32_t)((budget - fixed) / (chain_lds_bytes(1) - fixed)) : 0;
+        items = std::min<uint32_t>(items, kChainMaxItems);
+        if (items >= 8 && (coop || !c->chain_coop)) {
+            c->chain_items = items;
+            c->chain_lds = chain_lds_bytes(items);
+            if (hipFuncSetAttribute((const void *)fuse_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)c->chain_lds) != hipSuccess) {
+                (void)hipGetLastError();
+                c->chain_items = 0;
+            }
+        }
+    }
+    if (const char *e = std::getenv("SFM_FUSE_CHAIN")) c->chain = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SFM_CHAIN_COOP")) c->chain_coop = std::atoi(e) != 0;
     if (const char *e = std::getenv("SFM_TABLE_WGS")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 1024) c->table_wgs = (uint32_t)v;
@@ -562,7 +658,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     release(c->d_part); release(c->d_gorder); release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
     release(c->d_mark); release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_cand); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
-    release(c->d_qpix); release(c->d_qpw); release(c->d_qcount);
+    release(c->d_qpix); release(c->d_qpw); release(c->d_qcount); release(c->d_frames); release(c->d_bar);
     release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_group_end);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -661,6 +757,15 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
         if ((rc = run_once(c, table_cap, shard_cap, &err))) return rc;
         const bool crowded = !err && !fixed_tab && c->h_small->ctr.table_used * 2 > table_cap;
         if (!err && !crowded) break;
+        if (err & kErrBarrier) {
+            // The persistent kernel's workgroups were not all resident within the time limit (another
+            // process or stream holds CUs).  Nothing hangs: every workgroup has left.  This ctx goes
+            // on with the per-keyframe kernel pair, which needs no co-residency.
+            if (!c->chain) return fail(c, SFM_E_HIP, "device-wide barrier timed out");
+            c->chain = false;
+            c->chain_fallbacks++;
+            continue;
+        }
         if (err & kErrKeyRange)
             return fail(c, SFM_E_KEY_RANGE,
                         "a fused point's voxel index is outside the packed key range of +-(2^20-1) per axis");
@@ -711,7 +816,14 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     st.fuse_kernel_launches = 0;
     st.fuse_kernel_sum_ms = 0;
     st.scan_kernel_sum_ms = 0;
-    if (c->profile) {
+    st.fused_chain = c->chain_ran ? 1 : 0;
+    if (c->profile && c->chain_ran) {
+        for (size_t g = 0; g < (n + kGroup - 1) / kGroup; g++) {
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * g], c->kev[4 * g + 1]));
+            st.fuse_kernel_sum_ms += ms;
+            st.fuse_kernel_launches++;
+        }
+    } else if (c->profile) {
         for (size_t i = 0; i < n; i++) {
             if ((uint64_t)c->frames[i].W * c->frames[i].H == 0) continue;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * i], c->kev[4 * i + 1]));

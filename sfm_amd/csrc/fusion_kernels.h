@@ -22,6 +22,9 @@
 #else
 #define SFM_OBSERVE_OCC
 #endif
+#ifndef SFM_ABLATE
+#define SFM_ABLATE 0  // diagnostic builds only: removes one cost of fuse_chain_kernel's step B (results are wrong)
+#endif
 #ifndef SFM_STAMPS
 #define SFM_STAMPS 0  // diagnostic build only (tools_stamps.sh): per-wave phase timestamps of one launch
 #endif
@@ -45,6 +48,7 @@ constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr uint32_t kErrTableFull = 1u;
 constexpr uint32_t kErrKeyRange = 2u;
 constexpr uint32_t kErrListFull = 4u;
+constexpr uint32_t kErrBarrier = 8u;  // fuse_chain_kernel: a device-wide barrier timed out
 
 struct FrameDev {
     double K[4];      // fx fy cx cy
@@ -125,16 +129,19 @@ __device__ __forceinline__ double cov_trace(const DevParams &P, int u, int v, do
 // Same value as cov_trace(), bit for bit, with the four divisions that depend on the depth
 // alone taken from the per-focal-length table e = ctab + 4*depth:
 //   e[0] = (J00*S0)*J00, e[1] = (J00*S1)*J00, e[2] = disparity^2, e[3] = (J22*S2)*J22.
-__device__ __forceinline__ double cov_trace_tab(const DevParams &P, int u, int v, const double *e)
+__device__ __forceinline__ double cov_trace_vals(const DevParams &P, int u, int v, double2 e01, double2 e23)
 {
-    const double2 e01 = *reinterpret_cast<const double2 *>(e);
-    const double2 e23 = *reinterpret_cast<const double2 *>(e + 2);
     const double dd = e23.x;
     const double J02 = ((double)(-u) * P.base_line) / dd;
     const double J12 = ((double)(-v) * P.base_line) / dd;
     const double P00 = e01.x + (J02 * P.S2) * J02;
     const double P11 = e01.y + (J12 * P.S2) * J12;
     return P00 + (P11 + e23.y);
+}
+
+__device__ __forceinline__ double cov_trace_tab(const DevParams &P, int u, int v, const double *e)
+{
+    return cov_trace_vals(P, u, v, *reinterpret_cast<const double2 *>(e), *reinterpret_cast<const double2 *>(e + 2));
 }
 
 // One entry per raw depth value for focal length f; the operations and their order are those
@@ -191,6 +198,22 @@ __device__ __forceinline__ bool axis_code(long long k, unsigned long long &code)
     return true;
 }
 
+// axis_code(voxel_index(coord, vs)) without 64-bit conversions: the packed key only holds indices
+// within +-(2^20 - 1) and the indefinite value (NaN, >= 2^64, <= -2^63 -- voxel_index's INT64_MIN cases).
+__device__ __forceinline__ bool axis_code_of(double coord, double vs, unsigned long long &code)
+{
+    const double q = coord / vs;
+    double t = trunc(q);
+    // [2^63, 2^64) converts to the size_t bits of the negative index t - 2^64 (exact subtraction)
+    if (t >= 9223372036854775808.0 && t < 18446744073709551616.0) t = t - 18446744073709551616.0;
+    if (t >= -1048575.0 && t <= 1048575.0) {
+        code = (unsigned long long)(unsigned int)(int)t & 0x1FFFFFull;
+        return true;
+    }
+    code = 0x100000ull;
+    return (q != q) || t >= 18446744073709551616.0 || t <= -9223372036854775808.0;
+}
+
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
 {
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
@@ -200,6 +223,34 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
 }
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+
+// Loads through pointers that were themselves loaded from memory (FrameDev fields) are "flat" to the
+// compiler; flat loads also count on lgkmcnt and so tie every scalar-load wait to the slowest
+// gather in flight.  All image/table memory is global: say so.
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ T ldg(const T *p)
+{
+    return *(const __attribute__((address_space(1))) T *)p;
+}
+__device__ __forceinline__ double2 ldg2(const double *p)
+{
+    const dbl2_t v = *(const __attribute__((address_space(1))) dbl2_t *)p;
+    return make_double2(v.x, v.y);
+}
+// visibility-mask accesses of fuse_chain_kernel: agent-scope relaxed atomics (write-through store,
+// cache-bypassing load), see the kernel's header comment
+__device__ __forceinline__ uint32_t mask_load_coherent(const uint8_t *p)
+{
+    return __hip_atomic_load((const __attribute__((address_space(1))) uint8_t *)p, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mask_store_coherent(uint8_t *p)
+{
+    __hip_atomic_store((__attribute__((address_space(1))) uint8_t *)p, (uint8_t)255, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
 
 __device__ __forceinline__ unsigned long long lanemask_lt()
 {
@@ -397,12 +448,7 @@ __device__ __forceinline__ void obs_finish(const FrameDev &L, const DevParams &P
     const double qx = row_apply(L.Twk, 0, qcx, qcy, qcz);
     const double qy = row_apply(L.Twk, 1, qcx, qcy, qcz);
     const double qz = row_apply(L.Twk, 2, qcx, qcy, qcz);
-    const double dd = e23.x;
-    const double J02 = ((double)(-p.ix) * P.base_line) / dd;
-    const double J12 = ((double)(-p.iy) * P.base_line) / dd;
-    const double P00 = e01.x + (J02 * P.S2) * J02;
-    const double P11 = e01.y + (J12 * P.S2) * J12;
-    const double wgt = P00 + (P11 + e23.y);                              // :202
+    const double wgt = cov_trace_vals(P, p.ix, p.iy, e01, e23);          // :202
     kept = p.vis && (wgt < P.T_cov);                                     // :204
     const double dx = qx - pwx, dy = qy - pwy, dz = qz - pwz;
     const double s = (dx * dx + dy * dy) + dz * dz;                      // norm(): (e0+e1)+e2
@@ -486,16 +532,14 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
             const FrameDev &L1 = nbp[has1 ? k1 : k0];
             ObsProj p0 = obs_project(L0, pwx, pwy, pwz, act);
             ObsProj p1 = obs_project(L1, pwx, pwy, pwz, act && has1);
-            const uint32_t draw0 = L0.depth[p0.npix];                    // :193 (no d>0 test)
-            const uint32_t draw1 = L1.depth[p1.npix];
-            const double x0 = L0.xtab[p0.ix], y0 = L0.ytab[p0.iy];
-            const double x1 = L1.xtab[p1.ix], y1 = L1.ytab[p1.iy];
+            const uint32_t draw0 = ldg(L0.depth + p0.npix);              // :193 (no d>0 test)
+            const uint32_t draw1 = ldg(L1.depth + p1.npix);
+            const double x0 = ldg(L0.xtab + p0.ix), y0 = ldg(L0.ytab + p0.iy);
+            const double x1 = ldg(L1.xtab + p1.ix), y1 = ldg(L1.ytab + p1.iy);
             const double *e0 = L0.ctab + 4 * (size_t)draw0;
             const double *e1 = L1.ctab + 4 * (size_t)draw1;
-            const double2 e0a = *reinterpret_cast<const double2 *>(e0);
-            const double2 e0b = *reinterpret_cast<const double2 *>(e0 + 2);
-            const double2 e1a = *reinterpret_cast<const double2 *>(e1);
-            const double2 e1b = *reinterpret_cast<const double2 *>(e1 + 2);
+            const double2 e0a = ldg2(e0), e0b = ldg2(e0 + 2);
+            const double2 e1a = ldg2(e1), e1b = ldg2(e1 + 2);
             bool kept0, close0, kept1, close1;
             obs_finish(L0, P, p0, draw0, x0, y0, e0a, e0b, pwx, pwy, pwz, s_obs + (size_t)k0 * 256 + lane,
                        s_hit + k0 * 64 + lane, kept0, close0);
@@ -531,7 +575,8 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
         for (uint32_t k = w; k < K; k += NW) {
             const bool hitk = ok && ((s_kept[k] >> lane) & 1ull);
             c_hit += (unsigned)__popcll(__ballot(hitk));
-            if (hitk && nbp[k].order > F.order) nbp[k].mask[s_hit[k * 64 + lane]] = 255;
+            if (hitk && nbp[k].order > F.order)
+                *(__attribute__((address_space(1))) uint8_t *)(nbp[k].mask + s_hit[k * 64 + lane]) = 255;
         }
         SFM_STAMP(5);
         // one wave: weighted fusion in neighbour order (:157-165), voxel key, record
@@ -564,9 +609,8 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
             if (ok) {
                 fx = wx / total; fy = wy / total; fz = wz / total;           // :164
                 unsigned long long c0_, c1_, c2_;
-                const int fits = (int)axis_code(voxel_index(fx, P.voxel_size), c0_) &
-                                 (int)axis_code(voxel_index(fy, P.voxel_size), c1_) &
-                                 (int)axis_code(voxel_index(fz, P.voxel_size), c2_);
+                const int fits = (int)axis_code_of(fx, P.voxel_size, c0_) & (int)axis_code_of(fy, P.voxel_size, c1_) &
+                                 (int)axis_code_of(fz, P.voxel_size, c2_);
                 if (fits) {
                     key = (c0_ << 42) | (c1_ << 21) | c2_;
                     tag = ((unsigned long long)F.order << 32) | pix;
@@ -603,6 +647,463 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
         StatShard *st = &a.stat[(blockIdx.x * NW + w) % kStatShards];
         if (c_gather) atomicAdd(&st->n_gather, (unsigned long long)c_gather);
         if (c_hit) atomicAdd(&st->n_hit, (unsigned long long)c_hit);
+    }
+}
+
+// ---- the keyframe chain as one persistent launch ---------------------------------------------
+//
+// fuse_chain_kernel runs a whole group of keyframes in ONE launch: one 16-wave workgroup per CU,
+// all co-resident (cooperative launch), a device-wide barrier between keyframes instead of a
+// kernel boundary.  Per keyframe and workgroup:
+//   A  the workgroup's share of the image (64-pixel segments b, b+G, b+2G, ...: spread over the
+//      whole image so every workgroup sees the average live fraction): live test (:100-101),
+//      covariance gate (:136-140), back-projection (:143-144); survivors compacted into LDS;
+//   B  (chunk of 64 survivors, neighbour) items dealt round-robin to the 16 waves (:187-216);
+//   C  one wave per chunk: decision (:218-231), mask scatter (:152-154), fusion (:157-165),
+//      voxel key, record.
+// The only data that crosses workgroups inside a launch are the visibility masks.  They are
+// written and read with agent-scope relaxed atomics (write-through stores, cache-bypassing loads on
+// gfx950) and ordered by "wait until my stores are acknowledged, then arrive at the barrier":
+// no L2 write-back/invalidate is needed, which is what makes the barrier (about 2 us for 256
+// workgroups, tools/barrier_bench.hip) cheaper than a kernel boundary.  Every spin is bounded:
+// a workgroup that waits longer than kChainTimeoutTicks raises the abort flag and all leave.
+
+constexpr int kChainWaves = 16;
+constexpr int kChainThreads = kChainWaves * kWave;
+constexpr int kChainSegs = 2;                                    // segments per wave and pass
+constexpr int kChainSurv = 1024;                                 // survivors per batch (LDS); a pass with more runs in batches
+constexpr int kChainMaxItems = 64;                               // (chunk, neighbour) slots in LDS
+constexpr int kBarSub = 16;                                      // first-level barrier counters
+constexpr unsigned long long kChainTimeoutTicks = 5000000ull;    // 50 ms of the 100-MHz clock
+// barrier words, one per 64-B line: sub[kBarSub], top, flag, abort
+constexpr int kBarTop = kBarSub * 16, kBarFlag = kBarTop + 16, kBarAbort = kBarFlag + 16;
+constexpr size_t kBarBytes = (size_t)(kBarAbort + 16) * sizeof(unsigned int);
+
+struct ChainArgs {
+    uint32_t f0, f1;           // keyframes [f0, f1) of this launch
+    uint32_t item_cap;         // (chunk, neighbour) observation slots that fit in LDS
+    uint32_t pad;
+    ListDev list;
+    StatShard *stat;
+    unsigned int *bar;
+    DevParams P;
+#if SFM_STAMPS
+    unsigned long long *stamps;  // [f1 - f0][gridDim.x][16] 100-MHz timestamps of thread 0, or nullptr
+#endif
+};
+
+#if SFM_STAMPS
+#define SFM_BSTAMP(t, j)                                                                           \
+    do {                                                                                           \
+        if (a.stamps && lane == 0 && f == a.f0 + 16 && (t) < 8)                                    \
+            a.stamps[(size_t)kGroup * gridDim.x * 16 + (((size_t)blockIdx.x * 16 + w) * 8 + (t)) * 4 + (j)] = \
+                __builtin_amdgcn_s_memrealtime();                                                  \
+    } while (0)
+#define SFM_CSTAMP(i)                                                                              \
+    do {                                                                                           \
+        if (a.stamps && threadIdx.x == 0)                                                          \
+            a.stamps[((size_t)(f - a.f0) * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define SFM_CSTAMP(i) do {} while (0)
+#define SFM_BSTAMP(t, j) do {} while (0)
+#endif
+
+__host__ __device__ inline size_t chain_lds_bytes(uint32_t item_cap)
+{
+    return (size_t)kChainSurv * (3 * 8 + 4) + (size_t)item_cap * (4 * 64 * 8 + 64 * 4 + 16) + kMaxK * 8 +
+           2 * kChainWaves * kWave * 4 + 64;
+}
+
+__device__ __forceinline__ unsigned bar_load(const unsigned int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// thread 0 of every workgroup, once per keyframe; the caller has waited for its own stores
+__device__ __forceinline__ void chain_arrive(unsigned int *bar, unsigned G, unsigned epoch)
+{
+    const unsigned s = blockIdx.x % kBarSub;
+    const unsigned members = G / kBarSub + (s < G % kBarSub ? 1u : 0u);
+    const unsigned prev = __hip_atomic_fetch_add(bar + s * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == epoch * members - 1u) {
+        const unsigned subs = G < (unsigned)kBarSub ? G : (unsigned)kBarSub;
+        const unsigned p2 = __hip_atomic_fetch_add(bar + kBarTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p2 == epoch * subs - 1u)
+            __hip_atomic_store(bar + kBarFlag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ __forceinline__ bool chain_wait(unsigned int *bar, unsigned epoch)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+    while (bar_load(bar + kBarFlag) < epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 31u) == 0u) {
+            if (bar_load(bar + kBarAbort) != 0u) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kChainTimeoutTicks) {
+                __hip_atomic_store(bar + kBarAbort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+// The part of step A that does not depend on the visibility masks, for the workgroup's pixels of
+// one pass: validity (:100-101 without the mask), covariance gate (:136-140), back-projection
+// (:143-144).  It runs for keyframe f+1 while the workgroup waits at the barrier after keyframe f.
+// Pixels are dealt in pieces of 16: piece r of workgroup b is G*r + (b + 97 r) mod G, so that a run
+// of live pixels is shared by several workgroups and every workgroup samples the whole image.
+constexpr int kPiece = 16;
+struct ChainPre {
+    uint32_t pixel[kChainSegs];
+    bool cand[kChainSegs];                 // in the image, depth > 0, gate passed
+    double pwx[kChainSegs], pwy[kChainSegs], pwz[kChainSegs];
+};
+
+__device__ __forceinline__ uint32_t chain_slots(const FrameDev &F, unsigned G)
+{
+    if (F.nbr_count == 0) return 0u;  // a keyframe without neighbours yields nothing (:180)
+    const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
+    const uint32_t npieces = (npx + kPiece - 1) / kPiece;
+    const uint32_t piece_rounds = (npieces + G - 1) / G;
+    return (piece_rounds + (kWave / kPiece) - 1) / (kWave / kPiece);  // 64-lane slots per workgroup
+}
+
+__device__ __forceinline__ void chain_prepare(const FrameDev &F, const DevParams &P, uint32_t i0, unsigned w,
+                                              unsigned lane, unsigned b, unsigned G, ChainPre &r)
+{
+    const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
+    const uint32_t slots = chain_slots(F, G);
+    // slots == 0 (no pixels or no neighbours): every lane reads element 0, which the host keeps
+    // readable even for an empty image (build_layout)
+    uint32_t dv[kChainSegs];
+#pragma unroll
+    for (int u = 0; u < kChainSegs; u++) {
+        const uint32_t i = i0 + (uint32_t)u * kChainWaves + w;
+        const uint32_t pr = i * (kWave / kPiece) + lane / kPiece;
+        const uint32_t piece = G * pr + (b + 97u * pr) % G;
+        r.pixel[u] = piece * kPiece + lane % kPiece;
+        r.cand[u] = (i < slots) && (r.pixel[u] < npx);
+        dv[u] = ldg(F.depth + (r.cand[u] ? r.pixel[u] : 0u));
+    }
+    double2 e01[kChainSegs], e23[kChainSegs];
+    double xn[kChainSegs], yn[kChainSegs];
+    int uu[kChainSegs], vv[kChainSegs];
+#pragma unroll
+    for (int u = 0; u < kChainSegs; u++) {
+        r.cand[u] = r.cand[u] && (dv[u] > 0u);                                // :101
+        const double *e = F.ctab + 4 * (size_t)(r.cand[u] ? dv[u] : 1u);
+        e01[u] = ldg2(e);
+        e23[u] = ldg2(e + 2);
+        uu[u] = r.cand[u] ? (int)(r.pixel[u] % (uint32_t)F.W) : 0;
+        vv[u] = r.cand[u] ? (int)(r.pixel[u] / (uint32_t)F.W) : 0;
+        xn[u] = ldg(F.xtab + uu[u]);                                          // pinhole.cpp:12
+        yn[u] = ldg(F.ytab + vv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kChainSegs; u++) {
+        const double tr = cov_trace_vals(P, uu[u], vv[u], e01[u], e23[u]);    // :136
+        r.cand[u] = r.cand[u] && !(tr > P.T_cov);                             // :138
+        const double dsrc = (double)dv[u];
+        const double pcx = xn[u] * dsrc, pcy = yn[u] * dsrc, pcz = dsrc;      // pinhole.cpp:15-19
+        r.pwx[u] = row_apply(F.Twk, 0, pcx, pcy, pcz);                        // :144
+        r.pwy[u] = row_apply(F.Twk, 1, pcx, pcy, pcz);
+        r.pwz[u] = row_apply(F.Twk, 2, pcx, pcy, pcz);
+    }
+}
+
+// frames = every keyframe in processing order, nbrpack = FrameDev copies of the filtered neighbours
+// (frames[i].nbr_begin ...); neither is written by any kernel.
+__global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDev *__restrict__ frames,
+                                                                   const FrameDev *__restrict__ nbrpack, ChainArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const unsigned lane = lane_id();
+    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned b = blockIdx.x, G = gridDim.x;
+    const DevParams &P = a.P;
+    double *s_pw = reinterpret_cast<double *>(smem);                         // [3][kChainSurv]
+    double *s_obs = s_pw + 3 * kChainSurv;                                   // [item_cap][4][64]
+    uint32_t *s_spix = reinterpret_cast<uint32_t *>(s_obs + (size_t)a.item_cap * 256);  // [kChainSurv]
+    uint32_t *s_hit = s_spix + kChainSurv;                                   // [item_cap][64]
+    unsigned long long *s_kept = reinterpret_cast<unsigned long long *>(s_hit + (size_t)a.item_cap * 64);
+    unsigned long long *s_close = s_kept + a.item_cap;
+    uint8_t **s_nbmask = reinterpret_cast<uint8_t **>(s_close + a.item_cap);  // [kMaxK] masks of later neighbours
+    // per chunk and lane: kept observations | close observations << 16, summed by LDS atomics while
+    // the items run; two buffers, a round clears the one the next round uses
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_nbmask + kMaxK);   // [2][kChainWaves][64]
+    unsigned int *s_misc = s_cnt + 2 * kChainWaves * kWave;                     // [0] survivors, [1] go
+    unsigned c_gather = 0, c_hit = 0, err = 0;
+    for (unsigned i = threadIdx.x; i < 2u * kChainWaves * kWave; i += kChainThreads) s_cnt[i] = 0;
+    unsigned round_no = 0;
+
+    ChainPre pre;
+    unsigned pf_v = 0;
+    chain_prepare(frames[a.f0], P, 0, w, lane, b, G, pre);
+    for (uint32_t f = a.f0; f < a.f1; f++) {
+        SFM_CSTAMP(0);
+        if (f > a.f0) {
+            // every workgroup arrived after keyframe f-1 (below); its mask stores are out
+            if (threadIdx.x == 0) s_misc[1] = chain_wait(a.bar, f - a.f0) ? 1u : 0u;
+            __syncthreads();
+            if (s_misc[1] == 0u) {  // workgroup-uniform
+                err |= kErrBarrier;
+                break;
+            }
+        }
+        SFM_CSTAMP(1);
+        asm volatile("" ::"v"(pf_v));  // the prefetch issued before the barrier is only retired here
+        const FrameDev &F = frames[f];
+        const uint32_t K = F.nbr_count;
+        const FrameDev *nbp = nbrpack + F.nbr_begin;
+        const uint32_t slots = chain_slots(F, G);
+        // masks are only ever read of keyframes still to come: the scatter skips the others
+        if (threadIdx.x < K)
+            s_nbmask[threadIdx.x] = nbp[threadIdx.x].order > F.order ? nbp[threadIdx.x].mask : nullptr;
+        for (uint32_t i0 = 0; i0 < slots; i0 += kChainWaves * kChainSegs) {
+            // A pass is tried whole (part 0); when more than kChainSurv of its pixels survive (only
+            // the first keyframes of a sequence), it is redone one segment per wave at a time
+            // (parts 1..kChainSegs), which always fits.
+            for (uint32_t part = 0; part <= (uint32_t)kChainSegs; part++) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_misc[0] = 0;
+            __syncthreads();
+            // ---- A: the mask-independent part was prepared ahead for the first pass
+            if (i0 || part) chain_prepare(F, P, i0, w, lane, b, G, pre);
+            uint32_t pos[kChainSegs], mv[kChainSegs];
+#pragma unroll
+            for (int u = 0; u < kChainSegs; u++)
+                mv[u] = mask_load_coherent(F.mask + (pre.cand[u] ? pre.pixel[u] : 0u));
+#pragma unroll
+            for (int u = 0; u < kChainSegs; u++) {
+                const bool pass = pre.cand[u] && (mv[u] == 0u) && (part == 0 || part == (uint32_t)u + 1);  // :100
+                const unsigned long long m = __ballot(pass);
+                unsigned base = 0;
+                if (m != 0ull) {
+                    if (lane == 0) base = atomicAdd(&s_misc[0], (unsigned)__popcll(m));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                }
+                pos[u] = pass ? base + (unsigned)__popcll(m & lanemask_lt()) : 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            SFM_CSTAMP(2);
+            const uint32_t n = s_misc[0];
+#if SFM_STAMPS
+            if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)(f - a.f0) * gridDim.x + blockIdx.x) * 16 + 7] = n;
+#endif
+            if (n > (uint32_t)kChainSurv) continue;  // part 0 only: redo in parts (workgroup-uniform)
+            {
+#pragma unroll
+                for (int u = 0; u < kChainSegs; u++) {
+                    if (pos[u] != 0xFFFFFFFFu) {
+                        s_spix[pos[u]] = pre.pixel[u];
+                        s_pw[pos[u]] = pre.pwx[u];
+                        s_pw[kChainSurv + pos[u]] = pre.pwy[u];
+                        s_pw[2 * kChainSurv + pos[u]] = pre.pwz[u];
+                    }
+                }
+                __syncthreads();
+                const uint32_t chunks = (n + kWave - 1) / kWave;
+                const uint32_t R = min(min((uint32_t)kChainWaves, a.item_cap / K), chunks);  // chunks per round (host: item_cap >= K)
+                for (uint32_t c0 = 0; c0 < chunks; c0 += R) {
+                    const uint32_t rc = min(R, chunks - c0);
+                    const uint32_t items = rc * K;
+                    // wave w finishes chunk c0+w: its list space and colours are requested now
+                    const bool fin = w < rc;
+                    const uint32_t cf = c0 + w;
+                    const uint32_t n_in = fin ? min(n - cf * kWave, (uint32_t)kWave) : 0u;
+                    const bool actf = lane < n_in;
+                    unsigned long long base_r = 0;
+                    uint32_t pixf = 0, col = 0;
+                    if (fin) {
+                        if (lane == 0) base_r = atomicAdd(&a.list.cursor[((b + cf) % kListShards) * 8], (unsigned long long)n_in);
+                        if (actf) {                                              // :170, features.cpp:76-80
+                            pixf = s_spix[cf * kWave + lane];
+                            const uint8_t *cp = F.bgr + 3ull * pixf;
+                            col = (uint32_t)ldg(cp) | ((uint32_t)ldg(cp + 1) << 8) | ((uint32_t)ldg(cp + 2) << 16);
+                        }
+                    }
+                    unsigned int *cnt_now = s_cnt + (round_no & 1u) * (kChainWaves * kWave);
+                    unsigned int *cnt_next = s_cnt + ((round_no + 1u) & 1u) * (kChainWaves * kWave);
+                    round_no++;
+                    // ---- B: item it = (chunk c0 + it / K, neighbour it % K).  A wave runs its items
+                    // w, w+16, ... as a three-stage software pipeline, so that arithmetic of one item
+                    // covers the two dependent gathers (depth, then covariance table) of the next ones:
+                    //   S1 projection, depth/x/y gathers   S2 table gather   S3 the rest (:193-216)
+                    {
+                        const uint32_t nit = items > w ? (items - w + kChainWaves - 1) / kChainWaves : 0u;
+                        ObsProj p1, p2;
+                        p1.npix = p2.npix = 0; p1.ix = p1.iy = p2.ix = p2.iy = 0; p1.vis = p2.vis = false;
+                        uint32_t it1 = 0, it2 = 0, draw1 = 0, draw2 = 0;
+                        bool v1 = false, v2 = false;  // wave-uniform: stage holds an item
+                        double x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+                        double2 e2a = make_double2(0, 0), e2b = make_double2(0, 0);
+                        // fully unrolled (a wave has at most kChainMaxItems / kChainWaves items): no loop
+                        // back-edge at which the compiler would have to drain the loads in flight
+#pragma unroll
+                        for (uint32_t t = 0; t < (uint32_t)(kChainMaxItems / kChainWaves) + 2; t++) {
+                            SFM_BSTAMP(t, 0);
+                            // S2 of item t-1.  The vector loads of S1 and S2 are issued on every
+                            // iteration (element 0 for an empty stage): their number per iteration is
+                            // fixed, so every wait can name exactly the load it needs
+                            const double *e = nbp[it1 % K].ctab + 4 * (size_t)draw1;
+                            const double2 e1a = ldg2(e), e1b = ldg2(e + 2);
+                            SFM_BSTAMP(t, 1);
+                            // S1 of item t
+                            const bool v0 = t < nit;
+                            const uint32_t it0 = v0 ? w + t * kChainWaves : it1;
+                            const FrameDev &L = nbp[it0 % K];
+                            ObsProj p0;
+                            p0.npix = 0; p0.ix = p0.iy = 0; p0.vis = false;
+                            if (v0) {
+                                const uint32_t c = c0 + it0 / K;
+                                const uint32_t si = min(c * kWave + lane, (uint32_t)kChainSurv - 1);
+                                p0 = obs_project(L, s_pw[si], s_pw[kChainSurv + si], s_pw[2 * kChainSurv + si],
+                                                 c * kWave + lane < n);
+                            }
+                            const uint32_t draw0 = ldg(L.depth + p0.npix);       // :193 (no d>0 test)
+                            const double x0 = ldg(L.xtab + p0.ix);
+                            const double y0 = ldg(L.ytab + p0.iy);
+                            SFM_BSTAMP(t, 2);
+                            // S3 of item t-2
+                            if (v2) {
+                                const uint32_t c = it2 / K;
+                                const uint32_t si = min((c0 + c) * kWave + lane, (uint32_t)kChainSurv - 1);
+                                bool kept, close;
+                                obs_finish(nbp[it2 % K], P, p2, draw2, x2, y2, e2a, e2b, s_pw[si], s_pw[kChainSurv + si],
+                                           s_pw[2 * kChainSurv + si], s_obs + (size_t)it2 * 256 + lane, s_hit + it2 * 64 + lane,
+                                           kept, close);
+                                const unsigned long long mk = __ballot(kept);
+                                c_gather += (unsigned)__popcll(__ballot(p2.vis));
+                                if (kept) atomicAdd(&cnt_now[c * kWave + lane], close ? 0x10001u : 1u);
+                                if (lane == 0) s_kept[it2] = mk;
+                            }
+                            SFM_BSTAMP(t, 3);
+                            p2 = p1; it2 = it1; v2 = v1; draw2 = draw1; x2 = x1; y2 = y1; e2a = e1a; e2b = e1b;
+                            p1 = p0; it1 = it0; v1 = v0; draw1 = draw0; x1 = x0; y1 = y0;
+                        }
+                    }
+                    __syncthreads();
+                    SFM_CSTAMP(3);
+                    // ---- C: every wave scatters the masks of its own items (:152-154) ...
+                    for (uint32_t it = w; it < items; it += kChainWaves) {
+                        const uint32_t c = it / K, k = it % K;
+                        const unsigned pc = cnt_now[c * kWave + lane];
+                        const unsigned long long mk = s_kept[it];
+                        uint8_t *mp = s_nbmask[k];
+                        const uint32_t hp = s_hit[it * 64 + lane];
+                        const unsigned n_obs = pc & 0xFFFFu, n_close = pc >> 16;
+                        bool okc = n_obs >= 1;                                               // :218
+                        if ((double)n_close < (double)n_obs * P.close_frac) okc = false;     // :229
+                        const bool hitk = okc && ((mk >> lane) & 1ull);
+                        c_hit += (unsigned)__popcll(__ballot(hitk));
+                        if (hitk && mp) mask_store_coherent(mp + hp);
+                    }
+                    cnt_next[w * kWave + lane] = 0;  // all 16 chunk rows of the next round's buffer
+                    // ... and one wave per chunk forms the fused point and its record
+                    if (fin) {
+                        const uint32_t it0 = w * K;
+                        const unsigned pc = cnt_now[w * kWave + lane];
+                        const unsigned n_obs = pc & 0xFFFFu, n_close = pc >> 16;
+                        bool ok = actf && n_obs >= 1;                                        // :218
+                        if ((double)n_close < (double)n_obs * P.close_frac) ok = false;      // :229
+                        SFM_CSTAMP(9);
+                        // weighted fusion in neighbour order (:157-165); the LDS reads run ahead of the sums
+                        double wx = 0, wy = 0, wz = 0, total = 0;
+                        constexpr int kFuseBatch = 4;
+                        for (uint32_t kb = 0; kb < K; kb += kFuseBatch) {
+                            double ox[kFuseBatch], oy[kFuseBatch], oz[kFuseBatch], ow[kFuseBatch];
+                            bool on[kFuseBatch];
+#pragma unroll
+                            for (int i = 0; i < kFuseBatch; i++) {
+                                const uint32_t k = min(kb + i, K - 1);
+                                const double *o = s_obs + (size_t)(it0 + k) * 256 + lane;
+                                ox[i] = o[0]; oy[i] = o[64]; oz[i] = o[128]; ow[i] = o[192];
+                                on[i] = (kb + i < K) && ((s_kept[it0 + k] >> lane) & 1ull);
+                            }
+#pragma unroll
+                            for (int i = 0; i < kFuseBatch; i++) {
+                                wx = on[i] ? wx + ox[i] : wx;
+                                wy = on[i] ? wy + oy[i] : wy;
+                                wz = on[i] ? wz + oz[i] : wz;
+                                total = on[i] ? total + ow[i] : total;
+                            }
+                        }
+                        SFM_CSTAMP(10);
+                        unsigned long long key = 0, tag = kEmpty;
+                        double fx = 0, fy = 0, fz = 0;
+                        if (ok) {
+                            fx = wx / total; fy = wy / total; fz = wz / total;               // :164
+                            unsigned long long c0_, c1_, c2_;
+                            const int fits = (int)axis_code_of(fx, P.voxel_size, c0_) &
+                                             (int)axis_code_of(fy, P.voxel_size, c1_) &
+                                             (int)axis_code_of(fz, P.voxel_size, c2_);
+                            if (fits) {
+                                key = (c0_ << 42) | (c1_ << 21) | c2_;
+                                tag = ((unsigned long long)F.order << 32) | pixf;
+                            } else {
+                                err |= kErrKeyRange;
+                            }
+                        }
+                        SFM_CSTAMP(11);
+                        base_r = __shfl(base_r, 0);
+                        if (actf) {
+                            const unsigned long long rel = base_r + lane;
+                            if (rel < a.list.shard_cap) {
+                                const unsigned long long idx = (unsigned long long)((b + cf) % kListShards) * a.list.shard_cap + rel;
+                                a.list.tag[idx] = tag;
+                                if (tag != kEmpty) {
+                                    a.list.key[idx] = key;
+                                    a.list.xyz[3 * idx + 0] = fx;
+                                    a.list.xyz[3 * idx + 1] = fy;
+                                    a.list.xyz[3 * idx + 2] = fz;
+                                    a.list.bgr[idx] = col;
+                                }
+                            } else {
+                                err |= kErrListFull;
+                            }
+                        }
+                        SFM_CSTAMP(12);
+                    }
+                    __syncthreads();  // LDS slots are reused by the next round / part / pass
+                    SFM_CSTAMP(4);
+                }
+            }
+            if (part == 0) break;  // the whole pass fitted
+            }
+        }
+        SFM_CSTAMP(5);
+        if (f + 1 < a.f1) {
+            // my mask stores are acknowledged (write-through) before the workgroup arrives
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (threadIdx.x == 0) chain_arrive(a.bar, G, f - a.f0 + 1);
+            SFM_CSTAMP(6);
+            // while the others arrive: pull the next keyframe's neighbour descriptions into this
+            // XCD's L2 (they are read through the scalar cache right after the barrier) ...
+            {
+                const FrameDev &Fn = frames[f + 1];
+                const char *pf = reinterpret_cast<const char *>(nbrpack + Fn.nbr_begin);
+                if (threadIdx.x * 64u < Fn.nbr_count * (uint32_t)sizeof(FrameDev))
+                    pf_v = ldg(reinterpret_cast<const unsigned *>(pf + threadIdx.x * 64u));
+            }
+            // ... and do its mask-independent work
+            chain_prepare(frames[f + 1], P, 0, w, lane, b, G, pre);
+        }
+    }
+    const unsigned any_err = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(err != 0) != 0ull));
+    if (any_err) {
+        for (int o = 32; o > 0; o >>= 1) err |= __shfl_xor(err, o);
+    }
+    if (lane == 0 && (c_gather | c_hit | err)) {
+        StatShard *st = &a.stat[(b * kChainWaves + w) % kStatShards];
+        if (c_gather) atomicAdd(&st->n_gather, (unsigned long long)c_gather);
+        if (c_hit) atomicAdd(&st->n_hit, (unsigned long long)c_hit);
+        if (err) atomicOr(&st->err, err);
     }
 }
 

@@ -1,5 +1,7 @@
 """Shared helpers for the parity tests: run the HIP path through the C ABI and compare it
 with the CPU oracle (bit-exact for keys/tags/colours/counts AND coordinates)."""
+import os
+
 import numpy as np
 
 from oracle import oracle
@@ -25,6 +27,9 @@ def run_gpu(frames, gparams, device=0):
     st = ctx.stats()
     fb, fa = ctx.frame_counts()
     ctx.close()
+    want_path = os.environ.get("SFM_FUSE_CHAIN")
+    if want_path is not None and len(frames):
+        assert st["fused_chain"] == int(want_path != "0"), "the other keyframe-chain path ran"
     return dict(xyz=xyz, bgr=bgr, key=key, tag=tag, stats=st, frame_before=fb, frame_after=fa)
 
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Diagnostic: thread-0 phase timestamps of every workgroup of ONE fuse_chain_kernel launch (keyframe
+group SFM_STAMP_GROUP) from the -DSFM_STAMPS=1 build.  Run on the GPU box: python3 tools_chain_stamps.py [group]"""
+import os, subprocess, sys
+import numpy as np
+group = sys.argv[1] if len(sys.argv) > 1 else "9"
+out = "gpurun_out/cstamps_%s.bin" % group
+os.makedirs("gpurun_out", exist_ok=True)
+env = dict(os.environ, SFM_FUSION_LIB=os.path.abspath(os.environ.get("SFM_STAMPS_LIB", "build/stamps/libsfm_fusion_stamps.so")),
+           SFM_STAMP_GROUP=group, SFM_STAMP_OUT=out)
+subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env,
+               check=True, stdout=subprocess.DEVNULL)
+raw = np.fromfile(out, dtype=np.uint64).astype(np.int64)
+G = raw.size // (32 * 16 + 16 * 8 * 4)
+s = raw[:32 * G * 16].reshape(32, G, 16)
+bst = raw[32 * G * 16:].reshape(G, 16, 8, 4)
+t0 = s[0, :, 0].min()
+names = ["frame top", "barrier passed", "A done (survivors in LDS)", "B done (first round)", "C done (last round)",
+         "rounds done", "arrived", None, "C: decided", "C: masks issued", "C: sums done", "C: key done", "C: record issued"]
+print("workgroups", G)
+for f in (1, 2, 8, 16, 30):
+    fr = s[f]
+    base = fr[:, 0].min()
+    print("keyframe +%d: survivors per workgroup min %d mean %.0f max %d; frame span %.2f us" % (
+        f, fr[:, 7].min(), fr[:, 7].mean(), fr[:, 7].max(), (s[f + 1][:, 0].min() - base) / 100.0 if f + 1 < 32 else -1))
+    for i, n in enumerate(names):
+        if n is None: continue
+        col = (fr[:, i] - base) / 100.0
+        col = col[fr[:, i] > 0]
+        if len(col):
+            print("   %-28s min %6.2f  p50 %6.2f  max %6.2f" % (n, col.min(), np.percentile(col, 50), col.max()))
+per_frame = np.diff(s[:, :, 1].min(axis=1)) / 100.0
+print("per-keyframe period (first workgroup past the barrier): mean %.2f us  min %.2f  max %.2f" % (
+    per_frame[1:].mean(), per_frame[1:].min(), per_frame[1:].max()))
+
+# per-wave pipeline iterations of step B in keyframe +16: [workgroup][wave][iteration][top, S2 issued, S1 issued, S3 done]
+a_done = s[16][:, 2]
+print("step B of keyframe +16, per wave and pipeline iteration (us after the workgroup's A done; p50 over waves that ran it):")
+for t in range(6):
+    m = bst[:, :, t, 0] > 0
+    if not m.any():
+        continue
+    rel = (bst[:, :, t, :] - a_done[:, None, None]) / 100.0
+    print("  t=%d waves %5d  top %.2f  S2 issued %.2f  S1 issued %.2f  S3 done %.2f" % (
+        t, int(m.sum()), *[np.percentile(rel[:, :, j][m], 50) for j in range(4)]))

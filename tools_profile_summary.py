@@ -25,18 +25,22 @@ for name in ("fetch", "write"):
             agg[k][1] += 1
     pmc[name] = {k: dict(sum_kb=v[0], launches=v[1], kb_per_launch=v[0] / v[1]) for k, v in agg.items()}
 out["pmc"] = pmc
-k = "sfm::observe_frame_kernel"
+# the dominant kernel: the persistent chain kernel, or the observe kernel of the fallback pair
+k = "sfm::fuse_chain_kernel" if "sfm::fuse_chain_kernel" in pmc["fetch"] else "sfm::observe_frame_kernel"
+short = k.split("::")[1]
 fetch_kb = pmc["fetch"][k]["kb_per_launch"]
 write_kb = pmc["write"][k]["kb_per_launch"]
 # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies
 # 128-B requests at 64 B => doubled.  (Calibrated in the guide for wide streaming reads; this
 # kernel's 2-byte-per-lane reads and gathers are outside that calibration.)
 hbm = (2.0 * fetch_kb + write_kb) * 1024.0
-out["observe_frame_kernel_hbm_bytes_per_launch"] = hbm
-out["observe_frame_kernel_fetch_raw_bytes_per_launch"] = fetch_kb * 1024.0
-out["observe_frame_kernel_write_bytes_per_launch"] = write_kb * 1024.0
+out["dominant_kernel"] = short
+out[short + "_hbm_bytes_per_launch"] = hbm
+out[short + "_fetch_raw_bytes_per_launch"] = fetch_kb * 1024.0
+out[short + "_write_bytes_per_launch"] = write_kb * 1024.0
 json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 json.dump({"workload": out["workload"], "tag": tag, "hbm_bytes_per_launch": hbm,
-           "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per observe_frame_kernel launch, separate --pmc passes"},
+           "kernel": short,
+           "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of the dominant kernel, separate --pmc passes"},
           open("profiles/traffic_latest.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])

@@ -10,6 +10,6 @@ for cfg in "$@"; do
   echo "$line" | python3 -c "
 import sys,json
 j=json.loads(sys.stdin.read())
-print('$cfg', round(j['value']/1e9,3), round(j['ms_per_step'],3), round(j['roofline']['avg_launch_us'],2), round(j['roofline']['scan_kernel']['avg_launch_us'],2))" >> $out
+print('$cfg', round(j['value']/1e9,3), round(j['ms_per_step'],3), round(j['roofline']['avg_launch_us'],2), round((j['roofline']['scan_kernel'] or {'avg_launch_us':0})['avg_launch_us'],2))" >> $out
 done
 cat $out
