@@ -71,7 +71,12 @@ struct sfm_fusion_ctx {
     // keyframe chain: 1 = one persistent fuse_chain_kernel per group of keyframes (default when the
     // device can hold it), 0 = scan_frame_kernel + observe_frame_kernel per keyframe (SFM_FUSE_CHAIN)
     bool chain = true;
-    bool chain_coop = true;          // cooperative launch (SFM_CHAIN_COOP=0: plain launch)
+    // Plain launch by default: the grid is one workgroup per CU, each taking (nearly) the whole LDS
+    // of its CU, so it is co-resident whenever the device is not shared; every barrier spin is
+    // bounded, and a timeout sends the ctx to the kernel pair.  SFM_CHAIN_COOP=1 selects
+    // hipLaunchCooperativeKernel instead (about 4 % slower per launch here, and rocprofv3 7.2
+    // crashes in its finalizer after cooperative launches).
+    bool chain_coop = false;
     uint32_t chain_items = 0;        // (chunk, neighbour) LDS slots; 0 = chain kernel unusable here
     size_t chain_lds = 0;
     bool chain_ran = false;
