@@ -10,3 +10,7 @@ cp build/libsfm_fusion.so sfm_amd/lib/libsfm_fusion.so
 # C++ facade example (host-only code over the C ABI); run by tests/test_gpu_cpp_facade.py
 g++ -std=c++17 -O2 -Wall sfm_amd/cpp/facade_example.cpp -Lsfm_amd/lib -lsfm_fusion \
   -Wl,-rpath,'$ORIGIN/../lib' -o sfm_amd/cpp/facade_example
+g++ -std=c++17 -O2 -Wall sfm_amd/cpp/replay_reconstruct.cpp -Lsfm_amd/lib -lsfm_fusion \
+  -Wl,-rpath,'$ORIGIN/../lib' -o sfm_amd/cpp/replay_reconstruct
+# host-only formatter probe used by tests/test_writer_parity.py
+g++ -std=c++17 -O2 -Wall tests/cpp/writer_probe.cpp -o build/writer_probe

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <map>
+#include "cloud_writer.hpp"
 #include <ostream>
 #include <set>
 #include <stdexcept>
@@ -126,9 +127,13 @@ public:
     void reconstruct(std::ostream &os)
     {
         const Cloud c = fuse();
-        for (std::size_t i = 0; i < c.size(); i++)
-            os << c.xyz[3 * i] << ' ' << c.xyz[3 * i + 1] << ' ' << c.xyz[3 * i + 2] << ' '
-               << c.bgr[3 * i + 2] << ' ' << c.bgr[3 * i + 1] << ' ' << c.bgr[3 * i] << '\n';
+        write_text_fast(os, c.xyz.data(), c.bgr.data(), c.size());  // same bytes as write_text (cloud_writer.hpp)
+    }
+    // binary PLY instead of text (no reference counterpart)
+    void reconstruct_ply(std::ostream &os)
+    {
+        const Cloud c = fuse();
+        write_ply_binary(os, c.xyz.data(), c.bgr.data(), c.size());
     }
     const sfm_fusion_stats &stats() const { return stats_; }
 

@@ -214,6 +214,14 @@ __device__ __forceinline__ bool axis_code_of(double coord, double vs, unsigned l
     return (q != q) || t >= 18446744073709551616.0 || t <= -9223372036854775808.0;
 }
 
+// Every NaN the reference can produce on this path is x86's "real indefinite" (sign bit set, quiet,
+// zero payload: SSE2 returns it for 0*inf, inf-inf, inf/inf, and propagates it unchanged); gfx950
+// generates the positive quiet NaN.  The fused coordinates leave the kernels with the reference's bits.
+__device__ __forceinline__ double x86_nan(double v)
+{
+    return v != v ? __longlong_as_double((long long)0xFFF8000000000000ull) : v;
+}
+
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
 {
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
             unsigned long long key = 0, tag = kEmpty;
             double fx = 0, fy = 0, fz = 0;
             if (ok) {
-                fx = wx / total; fy = wy / total; fz = wz / total;           // :164
+                fx = x86_nan(wx / total); fy = x86_nan(wy / total); fz = x86_nan(wz / total);           // :164
                 unsigned long long c0_, c1_, c2_;
                 const int fits = (int)axis_code_of(fx, P.voxel_size, c0_) & (int)axis_code_of(fy, P.voxel_size, c1_) &
                                  (int)axis_code_of(fz, P.voxel_size, c2_);
@@ -1036,7 +1044,7 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
                         unsigned long long key = 0, tag = kEmpty;
                         double fx = 0, fy = 0, fz = 0;
                         if (ok) {
-                            fx = wx / total; fy = wy / total; fz = wz / total;               // :164
+                            fx = x86_nan(wx / total); fy = x86_nan(wy / total); fz = x86_nan(wz / total);               // :164
                             unsigned long long c0_, c1_, c2_;
                             const int fits = (int)axis_code_of(fx, P.voxel_size, c0_) &
                                              (int)axis_code_of(fy, P.voxel_size, c1_) &

@@ -15,6 +15,7 @@ every compute call needs a GPU.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from dataclasses import dataclass, field
 
@@ -347,12 +348,70 @@ class DenseReconstruction:
 
 
 def format_double(x: float) -> str:
-    """`os << double` with default precision(6), floatfield unset == printf("%g")."""
+    """`os << double` with default precision(6), floatfield unset == printf("%g").  glibc prints
+    the sign of a NaN ("-nan" for x86's indefinite NaN, which is what every NaN on this path is);
+    Python's %g drops it."""
+    x = float(x)
+    if x != x:
+        return "-nan" if math.copysign(1.0, x) < 0 else "nan"
     return "%g" % x
 
 
+def cloud_lines(xyz, bgr, sep=" "):
+    """The reference's writer loop, dense_reconstruction.cpp:61-64: x y z, then colour z,y,x
+    (= R G B), one line per point.  sep=", " gives the sparse-map variant (map.cpp:365-374)."""
+    xyz = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+    bgr = np.asarray(bgr).reshape(-1, 3)
+    fmt = sep.join(["%g", "%g", "%g", "%d", "%d", "%d"])
+    has_nan = np.isnan(xyz).any(axis=1) if len(xyz) else np.zeros(0, bool)
+    out = []
+    for i in range(len(xyz)):
+        if has_nan[i]:
+            out.append(sep.join([format_double(xyz[i, 0]), format_double(xyz[i, 1]), format_double(xyz[i, 2]),
+                                 str(int(bgr[i, 2])), str(int(bgr[i, 1])), str(int(bgr[i, 0]))]))
+        else:
+            out.append(fmt % (xyz[i, 0], xyz[i, 1], xyz[i, 2], bgr[i, 2], bgr[i, 1], bgr[i, 0]))
+    return out
+
+
 def write_cloud(os, xyz, bgr):
-    """dense_reconstruction.cpp:61-64: x y z then colour z,y,x (= R G B)."""
-    for p, c in zip(xyz, bgr):
-        os.write(f"{format_double(p[0])} {format_double(p[1])} {format_double(p[2])} "
-                 f"{int(c[2])} {int(c[1])} {int(c[0])}\n")
+    """Text cloud, byte-identical to the reference's writer (tests/test_writer_parity.py pins the
+    formatting against `std::ostream << double`)."""
+    lines = cloud_lines(xyz, bgr)
+    if lines:
+        os.write("\n".join(lines) + "\n")
+
+
+def write_sparse_csv(os, xyz, bgr):
+    """The comma-separated variant of the reference's sparse-map writer (map.cpp:365-374)."""
+    lines = cloud_lines(xyz, bgr, sep=", ")
+    if lines:
+        os.write("\n".join(lines) + "\n")
+
+
+def write_ply(fp, xyz, bgr):
+    """Binary little-endian PLY, lossless: double x/y/z, uchar red/green/blue (no reference
+    counterpart; same bytes as sfm_amd::write_ply_binary).  fp: a binary file object."""
+    xyz = np.ascontiguousarray(np.asarray(xyz, dtype="<f8").reshape(-1, 3))
+    bgr = np.asarray(bgr).reshape(-1, 3)
+    n = len(xyz)
+    fp.write(("ply\nformat binary_little_endian 1.0\ncomment fused by sfm_amd (MI355X dense fusion)\n"
+              "element vertex %d\nproperty double x\nproperty double y\nproperty double z\n"
+              "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % n).encode("ascii"))
+    rec = np.zeros(n, dtype=np.dtype([("xyz", "<f8", 3), ("rgb", "u1", 3)]))
+    rec["xyz"] = xyz
+    rec["rgb"] = bgr[:, ::-1].astype(np.uint8)
+    fp.write(rec.tobytes())
+
+
+def read_ply(fp):
+    """Reads what write_ply / write_ply_binary wrote: (xyz float64 [n,3], bgr int32 [n,3])."""
+    header = b""
+    while not header.endswith(b"end_header\n"):
+        line = fp.readline()
+        if not line:
+            raise ValueError("not a PLY written by sfm_amd")
+        header += line
+    n = int([ln.split()[2] for ln in header.decode("ascii").split("\n") if ln.startswith("element vertex")][0])
+    rec = np.frombuffer(fp.read(27 * n), dtype=np.dtype([("xyz", "<f8", 3), ("rgb", "u1", 3)]))
+    return rec["xyz"].copy(), rec["rgb"][:, ::-1].astype(np.int32)
