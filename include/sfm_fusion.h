@@ -112,6 +112,19 @@ int sfm_fusion_add_keyframe(sfm_fusion_ctx *ctx, uint32_t order_idx, int32_t W, 
 int sfm_fusion_set_neighbors(sfm_fusion_ctx *ctx, uint32_t order_idx,
                              const uint32_t *nbr_order_idx, uint32_t n);
 
+/* Alternative to one sfm_fusion_set_neighbors call per keyframe: hand over the covisibility
+ * graph itself -- `map.covisibility_edge` (include/reconstruction/map.hpp:143) as n_edges triples
+ * (a, b, shared count) over the order indices of ALL keyframes of the map, added with
+ * sfm_fusion_add_keyframe in map order -- and let the library apply the reference's rules:
+ * a keyframe is selected iff it is an endpoint of an edge with count >= select_min (100,
+ * src/dense_reconstruction.cpp:32-38); j is a neighbour of i iff count(i,j) > neighbor_min (100,
+ * src/dense_reconstruction.cpp:70, src/map.cpp:157), neighbours in ascending index order.
+ * Unselected keyframes produce nothing, are nobody's neighbour and do not count in n_px; tags
+ * keep the order index the keyframe was added with.  Replaces any earlier neighbour lists. */
+int sfm_fusion_set_covisibility(sfm_fusion_ctx *ctx, const uint32_t *edge_a, const uint32_t *edge_b,
+                                const uint32_t *edge_count, uint64_t n_edges, uint32_t select_min,
+                                uint32_t neighbor_min);
+
 /* Replaces the body of `reconstruct(std::ostream&)` up to the writer loop (:40-58):
  * zeroes the visibility masks, fuses every keyframe in order, applies the per-frame and the
  * global first-wins voxel filter.  May be called repeatedly (each call starts from clean

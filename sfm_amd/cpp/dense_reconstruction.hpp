@@ -107,10 +107,17 @@ public:
             check(sfm_fusion_add_keyframe(ctx, (std::uint32_t)i, k.width, k.height, k.depth, k.depth_step,
                                           k.img, k.img_step, K, k.T_wk, k.T_kw, SFM_MEM_HOST));
         }
+        // process_frame: map.get_neighbors(frame, 100) (:70) for every selected keyframe, in one
+        // pass over the edges (count > 100 implies both endpoints are selected); ascending order
+        std::vector<std::vector<std::uint32_t>> nb(order.size());
+        for (const auto &[e, count] : map_.covisibility_edge) {
+            if (count <= 100) continue;
+            nb[pos.at(e.first)].push_back(pos.at(e.second));
+            nb[pos.at(e.second)].push_back(pos.at(e.first));
+        }
         for (std::size_t i = 0; i < order.size(); i++) {
-            std::vector<std::uint32_t> nb;  // process_frame: map.get_neighbors(frame, 100)  (:70)
-            for (std::size_t j : map_.get_neighbors(order[i], 100)) nb.push_back(pos.at(j));
-            check(sfm_fusion_set_neighbors(ctx, (std::uint32_t)i, nb.data(), (std::uint32_t)nb.size()));
+            std::sort(nb[i].begin(), nb[i].end());
+            check(sfm_fusion_set_neighbors(ctx, (std::uint32_t)i, nb[i].data(), (std::uint32_t)nb[i].size()));
         }
         check(sfm_fusion_run(ctx));
         std::uint64_t n = 0;

@@ -34,6 +34,7 @@ struct HostFrame {
     uint16_t *d_depth = nullptr;
     uint8_t *d_bgr = nullptr;
     std::vector<uint32_t> nbrs;  // raw Map::get_neighbors list
+    bool selected = true;        // false: dropped by the selection rule (sfm_fusion_set_covisibility)
     uint32_t n_filtered = 0;     // neighbours left after the :72-89 filter
 };
 
@@ -218,7 +219,8 @@ int build_layout(sfm_fusion_ctx *c)
         total += ((uint64_t)c->frames[i].W * c->frames[i].H + 255) / 256 * 256;
     }
     c->total_px = 0;
-    for (auto &f : c->frames) c->total_px += (uint64_t)f.W * f.H;
+    for (auto &f : c->frames)
+        if (f.selected) c->total_px += (uint64_t)f.W * f.H;
     int rc;
     if ((rc = ensure(c, c->d_masks, total))) return rc;
     if ((rc = ensure(c, c->d_bar, kBarBytes / sizeof(unsigned int)))) return rc;
@@ -729,6 +731,42 @@ int sfm_fusion_set_neighbors(sfm_fusion_ctx *c, uint32_t order_idx, const uint32
     if (order_idx >= c->frames.size()) return fail(c, SFM_E_INVALID, "unknown keyframe");
     if (n && !nbr) return fail(c, SFM_E_INVALID, "null neighbour list");
     c->frames[order_idx].nbrs.assign(nbr, nbr + n);
+    c->frames[order_idx].selected = true;
+    c->layout_dirty = true;
+    c->have_result = false;
+    return SFM_OK;
+}
+
+int sfm_fusion_set_covisibility(sfm_fusion_ctx *c, const uint32_t *edge_a, const uint32_t *edge_b,
+                                const uint32_t *edge_count, uint64_t n_edges, uint32_t select_min,
+                                uint32_t neighbor_min)
+{
+    if (!c) return SFM_E_INVALID;
+    if (n_edges && (!edge_a || !edge_b || !edge_count)) return fail(c, SFM_E_INVALID, "null edge array");
+    const size_t n = c->frames.size();
+    for (uint64_t e = 0; e < n_edges; e++) {
+        if (edge_a[e] >= n || edge_b[e] >= n) return fail(c, SFM_E_INVALID, "edge names an unknown keyframe");
+        if (edge_a[e] == edge_b[e]) return fail(c, SFM_E_INVALID, "a keyframe cannot be its own neighbour");
+    }
+    for (auto &f : c->frames) {
+        f.nbrs.clear();
+        f.selected = false;
+    }
+    for (uint64_t e = 0; e < n_edges; e++) {
+        HostFrame &fa = c->frames[edge_a[e]], &fb = c->frames[edge_b[e]];
+        if (edge_count[e] >= select_min) fa.selected = fb.selected = true;  // dense_reconstruction.cpp:32-38
+        if (edge_count[e] > neighbor_min) {                                 // map.cpp:157
+            fa.nbrs.push_back(edge_b[e]);
+            fb.nbrs.push_back(edge_a[e]);
+        }
+    }
+    for (auto &f : c->frames) {
+        // canonical neighbour order: ascending keyframe index; the first insertion of
+        // an edge wins in the reference (map.cpp:108-119), so a repeated pair counts once
+        std::sort(f.nbrs.begin(), f.nbrs.end());
+        f.nbrs.erase(std::unique(f.nbrs.begin(), f.nbrs.end()), f.nbrs.end());
+        if (!f.selected) f.nbrs.clear();
+    }
     c->layout_dirty = true;
     c->have_result = false;
     return SFM_OK;

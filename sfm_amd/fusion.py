@@ -36,7 +36,7 @@ EXPORTS = [
     "sfm_fusion_num_points", "sfm_fusion_read_points", "sfm_fusion_get_stats",
     "sfm_fusion_get_frame_counts", "sfm_fusion_last_error", "sfm_fusion_version",
     "sfm_fusion_set_profiling", "sfm_fusion_set_global_order", "sfm_fusion_partition_counts",
-    "sfm_fusion_export_records", "sfm_fusion_merge",
+    "sfm_fusion_export_records", "sfm_fusion_merge", "sfm_fusion_set_covisibility",
 ]
 SFM_RECORD_BYTES = 48
 
@@ -94,6 +94,7 @@ def load_library():
     L.sfm_fusion_destroy.restype = None
     L.sfm_fusion_add_keyframe.argtypes = [vp, u32, i32, i32, vp, C.c_size_t, vp, C.c_size_t, dp, dp, dp, C.c_int]
     L.sfm_fusion_set_neighbors.argtypes = [vp, u32, C.POINTER(u32), u32]
+    L.sfm_fusion_set_covisibility.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), u64, u32, u32]
     L.sfm_fusion_run.argtypes = [vp]
     L.sfm_fusion_num_points.argtypes = [vp, C.POINTER(u64)]
     L.sfm_fusion_read_points.argtypes = [vp, vp, vp, vp, vp]
@@ -194,6 +195,16 @@ class FusionContext:
         nb = np.ascontiguousarray(nbrs, dtype=np.uint32)
         self._check(self._L.sfm_fusion_set_neighbors(
             self._h, int(idx), nb.ctypes.data_as(C.POINTER(C.c_uint32)), nb.size))
+
+    def set_covisibility(self, edges, select_min=100, neighbor_min=100):
+        """edges: iterable of (a, b, count) over the order indices of every keyframe added; the
+        library applies the selection (>= select_min) and neighbour (> neighbor_min) rules."""
+        e = np.ascontiguousarray(list(edges), dtype=np.uint32).reshape(-1, 3)
+        a, b, n = (np.ascontiguousarray(e[:, i]) for i in range(3))
+        p = C.POINTER(C.c_uint32)
+        self._check(self._L.sfm_fusion_set_covisibility(
+            self._h, a.ctypes.data_as(p), b.ctypes.data_as(p), n.ctypes.data_as(p), len(e), int(select_min),
+            int(neighbor_min)))
 
     def set_global_order(self, order):
         o = np.ascontiguousarray(order, dtype=np.uint32)
@@ -326,12 +337,22 @@ class DenseReconstruction:
                 sel.add(j)
         return sorted(sel)
 
-    def fuse(self):
+    def fuse(self, in_library_rules: bool = False):
         """Runs the GPU fusion; returns (xyz, bgr, key, tag) sorted by key.  Tags carry the
-        position in the selected-keyframe order."""
+        position in the selected-keyframe order -- or, with in_library_rules, the keyframe's index
+        in the map: then every keyframe and the raw edge counts are handed to the library, which
+        applies the selection and neighbour rules itself (sfm_fusion_set_covisibility)."""
         self.selected = self._select()
-        pos = {k: n for n, k in enumerate(self.selected)}
         self.ctx = FusionContext(self.params, self.device)
+        if in_library_rules:
+            for kf in self.map.keyframes:
+                self.ctx.add_keyframe(kf.get_depth_image(), kf.img, kf.camera_calibration(),
+                                      kf.transform(), kf.world_to_camera())
+            self.ctx.set_covisibility([(a, b, n) for (a, b), n in self.map.covisibility_edge.items()],
+                                      self.SELECT_MIN, self.NEIGHBOR_MIN)
+            self.ctx.run()
+            return self.ctx.read_points()
+        pos = {k: n for n, k in enumerate(self.selected)}
         for k in self.selected:
             kf = self.map.keyframes[k]
             self.ctx.add_keyframe(kf.get_depth_image(), kf.img, kf.camera_calibration(),

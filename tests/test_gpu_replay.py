@@ -61,3 +61,38 @@ def test_cli_from_replay_dump(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr
     assert open(out).read() == buf.getvalue()
+
+
+def test_in_library_selection_and_neighbour_rules():
+    """sfm_fusion_set_covisibility: all keyframes + raw edge counts in, the
+    library applies count >= 100 / count > 100 itself.  Same cloud as the facade-side rules; tags
+    carry map indices instead of positions in the selected order."""
+    m = small_map(n=6, W=64, H=48)
+    # two more keyframes that no edge >= 100 touches, in the middle of the order and at its end
+    f = m.keyframes[2]
+    m.keyframes.insert(3, fusion.KeyFrame(img=f.img, depth_img=f.depth_img, K=f.K, T_wk=f.T_wk, T_kw=f.T_kw))
+    old = dict(m.covisibility_edge)
+    m.covisibility_edge.clear()
+    m._adj.clear()
+    shift = lambda i: i + 1 if i >= 3 else i
+    for (a, b), n in old.items():
+        m.insert_edge(shift(a), shift(b), n)
+    m.insert_edge(3, 0, 42)
+    params = fusion.default_params(voxel_size=10.0, T_dist=500.0)
+    d1 = fusion.DenseReconstruction(m, params)
+    xyz1, bgr1, key1, tag1 = d1.fuse()
+    st1 = d1.ctx.stats()
+    d2 = fusion.DenseReconstruction(m, params)
+    xyz2, bgr2, key2, tag2 = d2.fuse(in_library_rules=True)
+    st2 = d2.ctx.stats()
+    assert 3 not in d1.selected and len(d1.selected) == len(m.keyframes) - 1
+    assert np.array_equal(key1, key2) and np.array_equal(bgr1, bgr2)
+    assert np.array_equal(xyz1.view(np.uint64), xyz2.view(np.uint64))
+    sel = np.asarray(d1.selected, dtype=np.uint64)
+    assert np.array_equal((sel[(tag1 >> np.uint64(32)).astype(np.int64)] << np.uint64(32)) | (tag1 & np.uint64(0xFFFFFFFF)), tag2)
+    for k in ("n_px", "n_gather", "n_acc", "n_hit", "n_vox", "global_before", "global_after"):
+        assert st1[k] == st2[k], k
+    want, _ = oracle_cloud(m, voxel_size=10.0, T_dist=500.0)
+    assert np.array_equal(key1, want.key) and np.array_equal(xyz1.view(np.uint64), want.xyz.view(np.uint64))
+    d1.ctx.close()
+    d2.ctx.close()
