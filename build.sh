@@ -14,3 +14,4 @@ g++ -std=c++17 -O2 -Wall sfm_amd/cpp/replay_reconstruct.cpp -Lsfm_amd/lib -lsfm_
   -Wl,-rpath,'$ORIGIN/../lib' -o sfm_amd/cpp/replay_reconstruct
 # host-only formatter probe used by tests/test_writer_parity.py
 g++ -std=c++17 -O2 -Wall tests/cpp/writer_probe.cpp -o build/writer_probe
+g++ -std=c++17 -O2 -Wall tests/cpp/recording_probe.cpp -lz -o build/recording_probe

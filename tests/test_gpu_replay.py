@@ -96,3 +96,25 @@ def test_in_library_selection_and_neighbour_rules():
     assert np.array_equal(key1, want.key) and np.array_equal(xyz1.view(np.uint64), want.xyz.view(np.uint64))
     d1.ctx.close()
     d2.ctx.close()
+
+
+def test_fusion_from_a_png_recording(tmp_path):
+    """Disk to cloud: a recording written as color_N.png / depth_N.png, read
+    back by RecordingReader, fused -- same cloud as fusing the arrays it was written from."""
+    from PIL import Image
+    from sfm_amd import recording, synth
+    from helpers import assert_same_cloud, both_params, run_gpu
+    seq = synth.make_sequence(5, 64, 48, K=(157.5, 157.5, 31.5, 23.5), window=2)
+    frames = seq.frame_dicts()
+    d = str(tmp_path)
+    for i, f in enumerate(frames):
+        Image.fromarray(np.ascontiguousarray(f["bgr"][:, :, ::-1])).save(f"{d}/color_{i}.png")
+        Image.fromarray(f["depth"].astype(np.uint16)).save(f"{d}/depth_{i}.png")
+    rd = recording.RecordingReader(d)
+    loaded = []
+    while (fr := rd.read_frames()) is not None:
+        i = len(loaded)
+        loaded.append(dict(frames[i], bgr=fr[0], depth=fr[1]))
+    assert len(loaded) == len(frames)
+    op, gp = both_params(voxel_size=10.0, T_dist=500.0)
+    assert_same_cloud(run_gpu(loaded, gp), oracle.fuse(frames, op))
