@@ -4,7 +4,9 @@
 set -e
 cd "$(dirname "$0")"
 mkdir -p sfm_amd/lib build
-hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -Wall \
+# -amdgpu-atomic-optimizer-strategy=None: that pass rewrites a one-lane atomic into atomic + readfirstlane and so
+# forces a wait for the atomic's round trip right behind it; the kernels aggregate their atomics themselves
+hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None -fPIC -shared -std=c++17 -Wall \
   -save-temps=obj sfm_amd/csrc/fusion_capi.hip -o build/libsfm_fusion.so "$@"
 cp build/libsfm_fusion.so sfm_amd/lib/libsfm_fusion.so
 # C++ facade example (host-only code over the C ABI); run by tests/test_gpu_cpp_facade.py

@@ -85,7 +85,6 @@ struct sfm_fusion_ctx {
     std::vector<FrameDev> h_frames;  // device-side description of every keyframe (host copy)
     DevBuf<uint8_t> d_masks;
     DevBuf<Slot> d_table;
-    DevBuf<unsigned long long> d_mark;
     DevBuf<unsigned long long> d_list_key, d_list_tag, d_out_key, d_out_tag, d_cand;
     DevBuf<double> d_list_xyz, d_out_xyz;
     DevBuf<uint32_t> d_list_bgr, d_out_bgr;
@@ -331,7 +330,6 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     const uint64_t list_cap = shard_cap * kListShards;
     int rc;
     if ((rc = ensure(c, c->d_table, table_cap))) return rc;
-    if ((rc = ensure(c, c->d_mark, table_cap))) return rc;
     if ((rc = ensure(c, c->d_list_key, list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_tag, list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_xyz, 3 * list_cap))) return rc;
@@ -353,7 +351,6 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     HIP_TRY(c, hipEventRecord(c->ev[0], sa));
     if (c->d_masks.n) HIP_TRY(c, hipMemsetAsync(c->d_masks.p, 0, c->d_masks.n, sa));  // :40-45
     HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0xFF, table_cap * sizeof(Slot), sa));
-    HIP_TRY(c, hipMemsetAsync(c->d_mark.p, 0, table_cap * sizeof(unsigned long long), sa));
     HIP_TRY(c, hipMemsetAsync(c->d_small, 0, kSmallBytes, sa));
     if (n) {
         HIP_TRY(c, hipMemsetAsync(c->d_fbefore.p, 0, n * sizeof(unsigned long long), sa));
@@ -393,7 +390,6 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
 
     TableArgs t;
     t.table = c->d_table.p;
-    t.mark = c->d_mark.p;
     t.table_mask = table_cap - 1;
     t.list = list;
     t.ctr = dev_ctr(c);
@@ -427,12 +423,12 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
             static unsigned long long *d_cstamps = nullptr;
             const char *sg = std::getenv("SFM_STAMP_GROUP");
             if (sg && (size_t)std::atoi(sg) == g) {
-                const size_t bytes = (size_t)kGroup * c->n_cu * 16 * 8 + (size_t)c->n_cu * 16 * 8 * 4 * 8;
+                const size_t bytes = (size_t)kGroup * c->n_cu * 16 * 8;
                 if (!d_cstamps) (void)hipMalloc(&d_cstamps, bytes);
                 (void)hipMemsetAsync(d_cstamps, 0, bytes, sa);
                 ca.stamps = d_cstamps;
                 c->stamp_ptr = d_cstamps;
-                c->stamp_n = (size_t)kGroup * c->n_cu * 16 + (size_t)c->n_cu * 16 * 8 * 4;
+                c->stamp_n = (size_t)kGroup * c->n_cu * 16;
             }
 #endif
             HIP_TRY(c, hipMemsetAsync(c->d_bar.p, 0, kBarBytes, sa));
@@ -503,7 +499,8 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
             t.f0 = (uint32_t)g0;
             t.f1 = (uint32_t)g1;
             t.group = (uint32_t)g;
-            hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, kListShards), dim3(256), 0, sb, t);
+            if (!std::getenv("SFM_DIAG_SKIP_TABLE"))  // diagnostic only: timing of the chain without its co-runner (no output points)
+                hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, kListShards), dim3(256), 0, sb, t);
         }
     }
     HIP_TRY(c, hipGetLastError());
@@ -663,7 +660,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
         if (f.d_bgr) (void)hipFree(f.d_bgr);
     }
     release(c->d_part); release(c->d_gorder); release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
-    release(c->d_mark); release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
+    release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_cand); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
     release(c->d_qpix); release(c->d_qpw); release(c->d_qcount); release(c->d_frames); release(c->d_bar);
     release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_group_end);

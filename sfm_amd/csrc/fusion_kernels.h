@@ -25,6 +25,12 @@
 #ifndef SFM_ABLATE
 #define SFM_ABLATE 0  // diagnostic builds only: removes one cost of fuse_chain_kernel's step B (results are wrong)
 #endif
+#ifndef SFM_REPEAT_ABL
+#define SFM_REPEAT_ABL 0  // with SFM_REPEAT == 1: what the second (discarded) pass of step B leaves out
+#endif
+#ifndef SFM_REPEAT
+#define SFM_REPEAT 0  // diagnostic builds only: 1/2/3 run step B / the step-C fusion / the step-C scatter twice (same results)
+#endif
 #ifndef SFM_STAMPS
 #define SFM_STAMPS 0  // diagnostic build only (tools_stamps.sh): per-wave phase timestamps of one launch
 #endif
@@ -72,9 +78,11 @@ struct DevParams {
     double S0, S1, S2, depth_div, close_frac;
 };
 
-struct Slot {
-    unsigned long long key;  // packed 3x21-bit voxel key, kEmpty when free
-    unsigned long long tag;  // min over inserted (order<<32 | pixel); kEmpty when free
+struct Slot {  // 32 bytes: everything an insert touches sits in one 64-byte sector
+    unsigned long long key;   // packed 3x21-bit voxel key, kEmpty when free
+    unsigned long long tag;   // min over inserted (order<<32 | pixel); kEmpty when free
+    unsigned long long mark;  // (group+1) << 32 | bitmask of the group's keyframes that touched the voxel
+    unsigned long long pad;
 };
 
 struct StatShard {  // one 64-byte line per shard
@@ -701,12 +709,6 @@ struct ChainArgs {
 };
 
 #if SFM_STAMPS
-#define SFM_BSTAMP(t, j)                                                                           \
-    do {                                                                                           \
-        if (a.stamps && lane == 0 && f == a.f0 + 16 && (t) < 8)                                    \
-            a.stamps[(size_t)kGroup * gridDim.x * 16 + (((size_t)blockIdx.x * 16 + w) * 8 + (t)) * 4 + (j)] = \
-                __builtin_amdgcn_s_memrealtime();                                                  \
-    } while (0)
 #define SFM_CSTAMP(i)                                                                              \
     do {                                                                                           \
         if (a.stamps && threadIdx.x == 0)                                                          \
@@ -714,7 +716,6 @@ struct ChainArgs {
     } while (0)
 #else
 #define SFM_CSTAMP(i) do {} while (0)
-#define SFM_BSTAMP(t, j) do {} while (0)
 #endif
 
 __host__ __device__ inline size_t chain_lds_bytes(uint32_t item_cap)
@@ -823,6 +824,105 @@ __device__ __forceinline__ void chain_prepare(const FrameDev &F, const DevParams
     }
 }
 
+// Step B of fuse_chain_kernel: the (chunk, neighbour) items of one round.  Item (c, k) uses LDS slot
+// c*K + k (c counted within the round).  A wave runs its items as a three-stage software pipeline,
+// so that arithmetic of one item covers the two dependent gathers (depth, then covariance table)
+// of the next ones:   S1 projection, depth/x/y gathers   S2 table gather   S3 the rest (:193-216).
+// The pipeline is fully unrolled (a wave has at most kChainMaxItems / kChainWaves items) -- no loop
+// back-edge at which the compiler would have to drain the loads in flight -- and the vector loads of
+// S1/S2 are issued whether or not the stage holds an item (element 0 then), so that their number per
+// iteration is fixed and every wait can name exactly the load it needs.
+// UNI (K divides the 16 waves): wave w keeps ONE neighbour, k = w mod K, for all its items and takes
+// the chunks w/K, w/K + 16/K, ...: the neighbour's intrinsics and poses are loaded into SGPRs once
+// per round instead of once per item and stage.  Otherwise items w, w+16, ... in slot order.
+template <bool UNI>
+__device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, const DevParams &P, uint32_t K, uint32_t rc,
+                                            uint32_t c0, uint32_t n, unsigned w, unsigned lane, const double *s_pw,
+                                            double *s_obs, uint32_t *s_hit, unsigned long long *s_kept,
+                                            unsigned int *cnt_now, unsigned &c_gather, bool count)
+{
+    constexpr uint32_t kMaxIt = kChainMaxItems / kChainWaves;
+    const uint32_t items = rc * K;
+    const uint32_t g = UNI ? (uint32_t)kChainWaves / K : 0u;
+    const uint32_t k_w = UNI ? w % K : 0u, c_w = UNI ? w / K : 0u;
+    const uint32_t nit = UNI ? (c_w < rc ? (rc - c_w + g - 1) / g : 0u)
+                             : (items > w ? (items - w + kChainWaves - 1) / kChainWaves : 0u);
+    ObsProj p1, p2;
+    p1.npix = p2.npix = 0; p1.ix = p1.iy = p2.ix = p2.iy = 0; p1.vis = p2.vis = false;
+    uint32_t c1 = 0, c2 = 0, k1 = 0, k2 = 0, draw1 = 0, draw2 = 0;  // c: chunk within the round
+    bool v1 = false, v2 = false;  // wave-uniform: stage holds an item
+    double x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    double2 e2a = make_double2(0, 0), e2b = make_double2(0, 0);
+#pragma unroll
+    for (uint32_t t = 0; t < kMaxIt + 2; t++) {  // t is a compile-time constant in every copy
+        // S2 of item t-1
+        double2 e1a = make_double2(0, 0), e1b = make_double2(0, 0);
+        if (t >= 1 && t <= kMaxIt) {
+            const double *e = nbp[k1].ctab + 4 * (size_t)draw1;
+#if SFM_REPEAT_ABL & 1
+            if (!count) e = nbp[k1].ctab + 4 * (size_t)(1000u + lane);
+#endif
+            e1a = ldg2(e);
+            e1b = ldg2(e + 2);
+        }
+        // S1 of item t
+        const bool v0 = t < kMaxIt && t < nit;
+        uint32_t cc0 = c1, k0 = k1;
+        if (v0) {
+            if (UNI) {
+                cc0 = c_w + t * g;
+                k0 = k_w;
+            } else {
+                const uint32_t it = w + t * kChainWaves;
+                cc0 = it / K;
+                k0 = it - cc0 * K;
+            }
+        }
+        const FrameDev &L = nbp[k0];
+        ObsProj p0;
+        p0.npix = 0; p0.ix = p0.iy = 0; p0.vis = false;
+        if (v0) {
+            const uint32_t si = min((c0 + cc0) * kWave + lane, (uint32_t)kChainSurv - 1);
+            p0 = obs_project(L, s_pw[si], s_pw[kChainSurv + si], s_pw[2 * kChainSurv + si], (c0 + cc0) * kWave + lane < n);
+        }
+        uint32_t draw0 = 0;
+        double x0 = 0, y0 = 0;
+        if (t < kMaxIt) {
+#if SFM_REPEAT_ABL & 2
+            if (!count) { p0.npix = lane; p0.ix = (int)lane; p0.iy = (int)lane; }
+#endif
+            draw0 = ldg(L.depth + p0.npix);  // :193 (no d>0 test)
+            x0 = ldg(L.xtab + p0.ix);
+            y0 = ldg(L.ytab + p0.iy);
+        }
+        // S3 of item t-2
+        if (t >= 2 && v2) {
+            const uint32_t it = c2 * K + k2;
+            const uint32_t si = min((c0 + c2) * kWave + lane, (uint32_t)kChainSurv - 1);
+            bool kept, close;
+#if SFM_REPEAT_ABL & 4
+            if (!count) {  // no S3 arithmetic at all
+                asm volatile("" ::"v"(draw2), "v"(x2), "v"(y2), "v"(e2a.x), "v"(e2b.y));
+            } else
+#endif
+            {
+            ObsProj pq = p2;
+#if SFM_REPEAT == 1 && !(SFM_REPEAT_ABL & 8)
+            if (!count) pq.vis = false;  // the discarded pass computes, but keeps nothing and writes nothing
+#endif
+            obs_finish(nbp[k2], P, pq, draw2, x2, y2, e2a, e2b, s_pw[si], s_pw[kChainSurv + si], s_pw[2 * kChainSurv + si],
+                       s_obs + (size_t)it * 256 + lane, s_hit + it * 64 + lane, kept, close);
+            const unsigned long long mk = __ballot(kept);
+            if (count) c_gather += (unsigned)__popcll(__ballot(p2.vis));
+            if (kept && count) atomicAdd(&cnt_now[c2 * kWave + lane], close ? 0x10001u : 1u);
+            if (lane == 0 && count) s_kept[it] = mk;
+            }
+        }
+        p2 = p1; c2 = c1; k2 = k1; v2 = v1; draw2 = draw1; x2 = x1; y2 = y1; e2a = e1a; e2b = e1b;
+        p1 = p0; c1 = cc0; k1 = k0; v1 = v0; draw1 = draw0; x1 = x0; y1 = y0;
+    }
+}
+
 // frames = every keyframe in processing order, nbrpack = FrameDev copies of the filtered neighbours
 // (frames[i].nbr_begin ...); neither is written by any kernel.
 __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDev *__restrict__ frames,
@@ -919,84 +1019,25 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
                 for (uint32_t c0 = 0; c0 < chunks; c0 += R) {
                     const uint32_t rc = min(R, chunks - c0);
                     const uint32_t items = rc * K;
-                    // wave w finishes chunk c0+w: its list space and colours are requested now
+                    // wave w finishes chunk c0+w (step C)
                     const bool fin = w < rc;
                     const uint32_t cf = c0 + w;
                     const uint32_t n_in = fin ? min(n - cf * kWave, (uint32_t)kWave) : 0u;
                     const bool actf = lane < n_in;
-                    unsigned long long base_r = 0;
-                    uint32_t pixf = 0, col = 0;
-                    if (fin) {
-                        if (lane == 0) base_r = atomicAdd(&a.list.cursor[((b + cf) % kListShards) * 8], (unsigned long long)n_in);
-                        if (actf) {                                              // :170, features.cpp:76-80
-                            pixf = s_spix[cf * kWave + lane];
-                            const uint8_t *cp = F.bgr + 3ull * pixf;
-                            col = (uint32_t)ldg(cp) | ((uint32_t)ldg(cp + 1) << 8) | ((uint32_t)ldg(cp + 2) << 16);
-                        }
-                    }
                     unsigned int *cnt_now = s_cnt + (round_no & 1u) * (kChainWaves * kWave);
                     unsigned int *cnt_next = s_cnt + ((round_no + 1u) & 1u) * (kChainWaves * kWave);
                     round_no++;
-                    // ---- B: item it = (chunk c0 + it / K, neighbour it % K).  A wave runs its items
-                    // w, w+16, ... as a three-stage software pipeline, so that arithmetic of one item
-                    // covers the two dependent gathers (depth, then covariance table) of the next ones:
-                    //   S1 projection, depth/x/y gathers   S2 table gather   S3 the rest (:193-216)
-                    {
-                        const uint32_t nit = items > w ? (items - w + kChainWaves - 1) / kChainWaves : 0u;
-                        ObsProj p1, p2;
-                        p1.npix = p2.npix = 0; p1.ix = p1.iy = p2.ix = p2.iy = 0; p1.vis = p2.vis = false;
-                        uint32_t it1 = 0, it2 = 0, draw1 = 0, draw2 = 0;
-                        bool v1 = false, v2 = false;  // wave-uniform: stage holds an item
-                        double x1 = 0, y1 = 0, x2 = 0, y2 = 0;
-                        double2 e2a = make_double2(0, 0), e2b = make_double2(0, 0);
-                        // fully unrolled (a wave has at most kChainMaxItems / kChainWaves items): no loop
-                        // back-edge at which the compiler would have to drain the loads in flight
-#pragma unroll
-                        for (uint32_t t = 0; t < (uint32_t)(kChainMaxItems / kChainWaves) + 2; t++) {
-                            SFM_BSTAMP(t, 0);
-                            // S2 of item t-1.  The vector loads of S1 and S2 are issued on every
-                            // iteration (element 0 for an empty stage): their number per iteration is
-                            // fixed, so every wait can name exactly the load it needs
-                            const double *e = nbp[it1 % K].ctab + 4 * (size_t)draw1;
-                            const double2 e1a = ldg2(e), e1b = ldg2(e + 2);
-                            SFM_BSTAMP(t, 1);
-                            // S1 of item t
-                            const bool v0 = t < nit;
-                            const uint32_t it0 = v0 ? w + t * kChainWaves : it1;
-                            const FrameDev &L = nbp[it0 % K];
-                            ObsProj p0;
-                            p0.npix = 0; p0.ix = p0.iy = 0; p0.vis = false;
-                            if (v0) {
-                                const uint32_t c = c0 + it0 / K;
-                                const uint32_t si = min(c * kWave + lane, (uint32_t)kChainSurv - 1);
-                                p0 = obs_project(L, s_pw[si], s_pw[kChainSurv + si], s_pw[2 * kChainSurv + si],
-                                                 c * kWave + lane < n);
-                            }
-                            const uint32_t draw0 = ldg(L.depth + p0.npix);       // :193 (no d>0 test)
-                            const double x0 = ldg(L.xtab + p0.ix);
-                            const double y0 = ldg(L.ytab + p0.iy);
-                            SFM_BSTAMP(t, 2);
-                            // S3 of item t-2
-                            if (v2) {
-                                const uint32_t c = it2 / K;
-                                const uint32_t si = min((c0 + c) * kWave + lane, (uint32_t)kChainSurv - 1);
-                                bool kept, close;
-                                obs_finish(nbp[it2 % K], P, p2, draw2, x2, y2, e2a, e2b, s_pw[si], s_pw[kChainSurv + si],
-                                           s_pw[2 * kChainSurv + si], s_obs + (size_t)it2 * 256 + lane, s_hit + it2 * 64 + lane,
-                                           kept, close);
-                                const unsigned long long mk = __ballot(kept);
-                                c_gather += (unsigned)__popcll(__ballot(p2.vis));
-                                if (kept) atomicAdd(&cnt_now[c * kWave + lane], close ? 0x10001u : 1u);
-                                if (lane == 0) s_kept[it2] = mk;
-                            }
-                            SFM_BSTAMP(t, 3);
-                            p2 = p1; it2 = it1; v2 = v1; draw2 = draw1; x2 = x1; y2 = y1; e2a = e1a; e2b = e1b;
-                            p1 = p0; it1 = it0; v1 = v0; draw1 = draw0; x1 = x0; y1 = y0;
-                        }
+                    // ---- B: the (chunk, neighbour) items of this round (:187-216)
+                    for (int rep = 0; rep < (SFM_REPEAT == 1 ? 2 : 1); rep++) {
+                        if (kChainWaves % K == 0)
+                            chain_items<true>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, rep == 0);
+                        else
+                            chain_items<false>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, rep == 0);
                     }
                     __syncthreads();
                     SFM_CSTAMP(3);
                     // ---- C: every wave scatters the masks of its own items (:152-154) ...
+                    for (int rep = 0; rep < (SFM_REPEAT == 3 ? 2 : 1); rep++)
                     for (uint32_t it = w; it < items; it += kChainWaves) {
                         const uint32_t c = it / K, k = it % K;
                         const unsigned pc = cnt_now[c * kWave + lane];
@@ -1007,12 +1048,20 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
                         bool okc = n_obs >= 1;                                               // :218
                         if ((double)n_close < (double)n_obs * P.close_frac) okc = false;     // :229
                         const bool hitk = okc && ((mk >> lane) & 1ull);
-                        c_hit += (unsigned)__popcll(__ballot(hitk));
+                        if (rep == 0) c_hit += (unsigned)__popcll(__ballot(hitk));
                         if (hitk && mp) mask_store_coherent(mp + hp);
                     }
                     cnt_next[w * kWave + lane] = 0;  // all 16 chunk rows of the next round's buffer
                     // ... and one wave per chunk forms the fused point and its record
+                    for (int rep = 0; rep < (SFM_REPEAT == 2 ? 2 : 1); rep++)
                     if (fin) {
+                        // list space and colour (:170, features.cpp:76-80) are requested first and used
+                        // last: their round trips run under the sums and the divisions
+                        unsigned long long base_r = 0;
+                        if (lane == 0) base_r = atomicAdd(&a.list.cursor[((b + cf) % kListShards) * 8], (unsigned long long)n_in);
+                        const uint32_t pixf = s_spix[min(cf * kWave + lane, (uint32_t)kChainSurv - 1)];
+                        const uint8_t *cp = F.bgr + 3ull * (actf ? pixf : 0u);
+                        const uint32_t cb = ldg(cp), cg = ldg(cp + 1), cr = ldg(cp + 2);
                         const uint32_t it0 = w * K;
                         const unsigned pc = cnt_now[w * kWave + lane];
                         const unsigned n_obs = pc & 0xFFFFu, n_close = pc >> 16;
@@ -1068,7 +1117,7 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
                                     a.list.xyz[3 * idx + 0] = fx;
                                     a.list.xyz[3 * idx + 1] = fy;
                                     a.list.xyz[3 * idx + 2] = fz;
-                                    a.list.bgr[idx] = col;
+                                    a.list.bgr[idx] = cb | (cg << 8) | (cr << 16);
                                 }
                             } else {
                                 err |= kErrListFull;
@@ -1119,7 +1168,6 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
 
 struct TableArgs {
     Slot *table;
-    unsigned long long *mark;  // per slot: (group+1) << 32 | bitmask of the group's keyframes seen
     uint64_t table_mask;       // capacity-1
     ListDev list;
     Counters *ctr;
@@ -1188,12 +1236,12 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
                 // it goes on the candidate list that finalize_kernel walks.
                 lower = prev_tag > tag;
                 const unsigned long long bit = 1ull << fr;
-                unsigned long long old = a.mark[h];
+                unsigned long long old = a.table[h].mark;  // a fresh slot holds kEmpty: no group has that id
                 for (;;) {
                     const bool same = (old >> 32) == want_hi;
                     if (same && (old & bit)) break;
                     const unsigned long long neu = same ? (old | bit) : ((want_hi << 32) | bit);
-                    const unsigned long long prev = atomicCAS(&a.mark[h], old, neu);
+                    const unsigned long long prev = atomicCAS(&a.table[h].mark, old, neu);
                     if (prev == old) { atomicAdd(&s_after[fr], 1u); break; }
                     old = prev;
                 }

@@ -11,9 +11,8 @@ env = dict(os.environ, SFM_FUSION_LIB=os.path.abspath(os.environ.get("SFM_STAMPS
 subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env,
                check=True, stdout=subprocess.DEVNULL)
 raw = np.fromfile(out, dtype=np.uint64).astype(np.int64)
-G = raw.size // (32 * 16 + 16 * 8 * 4)
-s = raw[:32 * G * 16].reshape(32, G, 16)
-bst = raw[32 * G * 16:].reshape(G, 16, 8, 4)
+G = raw.size // (32 * 16)
+s = raw.reshape(32, G, 16)
 t0 = s[0, :, 0].min()
 names = ["frame top", "barrier passed", "A done (survivors in LDS)", "B done (first round)", "C done (last round)",
          "rounds done", "arrived", None, "C: decided", "C: masks issued", "C: sums done", "C: key done", "C: record issued"]
@@ -33,13 +32,3 @@ per_frame = np.diff(s[:, :, 1].min(axis=1)) / 100.0
 print("per-keyframe period (first workgroup past the barrier): mean %.2f us  min %.2f  max %.2f" % (
     per_frame[1:].mean(), per_frame[1:].min(), per_frame[1:].max()))
 
-# per-wave pipeline iterations of step B in keyframe +16: [workgroup][wave][iteration][top, S2 issued, S1 issued, S3 done]
-a_done = s[16][:, 2]
-print("step B of keyframe +16, per wave and pipeline iteration (us after the workgroup's A done; p50 over waves that ran it):")
-for t in range(6):
-    m = bst[:, :, t, 0] > 0
-    if not m.any():
-        continue
-    rel = (bst[:, :, t, :] - a_done[:, None, None]) / 100.0
-    print("  t=%d waves %5d  top %.2f  S2 issued %.2f  S1 issued %.2f  S3 done %.2f" % (
-        t, int(m.sum()), *[np.percentile(rel[:, :, j][m], 50) for j in range(4)]))
