@@ -17,3 +17,6 @@ g++ -std=c++17 -O2 -Wall sfm_amd/cpp/replay_reconstruct.cpp -Lsfm_amd/lib -lsfm_
 # host-only formatter probe used by tests/test_writer_parity.py
 g++ -std=c++17 -O2 -Wall tests/cpp/writer_probe.cpp -o build/writer_probe
 g++ -std=c++17 -O2 -Wall tests/cpp/recording_probe.cpp -lz -o build/recording_probe
+# fuse_chain_kernel must leave VGPRs for a co-resident table-kernel wave (see the kernel's comment)
+nv=$(grep -E "fuse_chain_kernel.*\.num_vgpr," build/fusion_capi-hip-amdgcn-amd-amdhsa-gfx950.s | head -1 | sed 's/.*num_vgpr, *//')
+if [ -n "$nv" ] && [ "$nv" -gt 120 ]; then echo "build.sh: fuse_chain_kernel uses $nv VGPRs (> 120)" >&2; exit 1; fi

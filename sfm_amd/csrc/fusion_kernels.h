@@ -925,6 +925,10 @@ __device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, co
 
 // frames = every keyframe in processing order, nbrpack = FrameDev copies of the filtered neighbours
 // (frames[i].nbr_begin ...); neither is written by any kernel.
+// Keep this kernel at or below 120 VGPRs (tools_isa_stats.py; __graft_entry__.build() checks it): with 4
+// waves per SIMD that leaves 32 of the 512 registers per lane for a wave of the table kernel of the
+// previous group.  At 121+ the allocation is 128, the CU is full, the chain workgroups cannot be placed
+// before that kernel has drained, and every launch loses its ~200 us.
 __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDev *__restrict__ frames,
                                                                    const FrameDev *__restrict__ nbrpack, ChainArgs a)
 {
@@ -955,7 +959,16 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
         SFM_CSTAMP(0);
         if (f > a.f0) {
             // every workgroup arrived after keyframe f-1 (below); its mask stores are out
+#if SFM_REPEAT == 5
+            if (threadIdx.x == 0) {  // diagnostic: a second, empty barrier behind the real one
+                bool okb = chain_wait(a.bar, 2 * (f - a.f0) - 1);
+                chain_arrive(a.bar, G, 2 * (f - a.f0));
+                okb = okb && chain_wait(a.bar, 2 * (f - a.f0));
+                s_misc[1] = okb ? 1u : 0u;
+            }
+#else
             if (threadIdx.x == 0) s_misc[1] = chain_wait(a.bar, f - a.f0) ? 1u : 0u;
+#endif
             __syncthreads();
             if (s_misc[1] == 0u) {  // workgroup-uniform
                 err |= kErrBarrier;
@@ -982,6 +995,17 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
             // ---- A: the mask-independent part was prepared ahead for the first pass
             if (i0 || part) chain_prepare(F, P, i0, w, lane, b, G, pre);
             uint32_t pos[kChainSegs], mv[kChainSegs];
+#if SFM_REPEAT == 4
+            {  // diagnostic: the mask read and a ballot once more, discarded
+                uint32_t mq[kChainSegs];
+#pragma unroll
+                for (int u = 0; u < kChainSegs; u++) mq[u] = mask_load_coherent(F.mask + (pre.cand[u] ? pre.pixel[u] : 0u));
+                unsigned long long acc = 0;
+#pragma unroll
+                for (int u = 0; u < kChainSegs; u++) acc += __ballot(pre.cand[u] && mq[u] == 0u);
+                if (acc == 0x123456789ull) err |= 16u;
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < kChainSegs; u++)
                 mv[u] = mask_load_coherent(F.mask + (pre.cand[u] ? pre.pixel[u] : 0u));
@@ -1003,6 +1027,10 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
             if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)(f - a.f0) * gridDim.x + blockIdx.x) * 16 + 7] = n;
 #endif
             if (n > (uint32_t)kChainSurv) continue;  // part 0 only: redo in parts (workgroup-uniform)
+            // list space for all survivors of this pass: one atomic per workgroup, issued now, its
+            // result parked in LDS after step B and used at the end of step C -- nobody waits for it
+            unsigned long long res_base = 0;
+            if (threadIdx.x == 0 && n) res_base = atomicAdd(&a.list.cursor[(b % kListShards) * 8], (unsigned long long)n);
             {
 #pragma unroll
                 for (int u = 0; u < kChainSegs; u++) {
@@ -1034,6 +1062,7 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
                         else
                             chain_items<false>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, rep == 0);
                     }
+                    if (threadIdx.x == 0 && c0 == 0) *reinterpret_cast<unsigned long long *>(s_misc + 2) = res_base;
                     __syncthreads();
                     SFM_CSTAMP(3);
                     // ---- C: every wave scatters the masks of its own items (:152-154) ...
@@ -1055,10 +1084,8 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
                     // ... and one wave per chunk forms the fused point and its record
                     for (int rep = 0; rep < (SFM_REPEAT == 2 ? 2 : 1); rep++)
                     if (fin) {
-                        // list space and colour (:170, features.cpp:76-80) are requested first and used
-                        // last: their round trips run under the sums and the divisions
-                        unsigned long long base_r = 0;
-                        if (lane == 0) base_r = atomicAdd(&a.list.cursor[((b + cf) % kListShards) * 8], (unsigned long long)n_in);
+                        // the colour (:170, features.cpp:76-80) is requested first and used last: its
+                        // round trip runs under the sums and the divisions
                         const uint32_t pixf = s_spix[min(cf * kWave + lane, (uint32_t)kChainSurv - 1)];
                         const uint8_t *cp = F.bgr + 3ull * (actf ? pixf : 0u);
                         const uint32_t cb = ldg(cp), cg = ldg(cp + 1), cr = ldg(cp + 2);
@@ -1106,11 +1133,10 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
                             }
                         }
                         SFM_CSTAMP(11);
-                        base_r = __shfl(base_r, 0);
                         if (actf) {
-                            const unsigned long long rel = base_r + lane;
+                            const unsigned long long rel = *reinterpret_cast<unsigned long long *>(s_misc + 2) + cf * kWave + lane;
                             if (rel < a.list.shard_cap) {
-                                const unsigned long long idx = (unsigned long long)((b + cf) % kListShards) * a.list.shard_cap + rel;
+                                const unsigned long long idx = (unsigned long long)(b % kListShards) * a.list.shard_cap + rel;
                                 a.list.tag[idx] = tag;
                                 if (tag != kEmpty) {
                                     a.list.key[idx] = key;
@@ -1138,7 +1164,11 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
+#if SFM_REPEAT == 5
+            if (threadIdx.x == 0) chain_arrive(a.bar, G, 2 * (f - a.f0) + 1);
+#else
             if (threadIdx.x == 0) chain_arrive(a.bar, G, f - a.f0 + 1);
+#endif
             SFM_CSTAMP(6);
             // while the others arrive: pull the next keyframe's neighbour descriptions into this
             // XCD's L2 (they are read through the scalar cache right after the barrier) ...

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 : > $out
 for cfg in "$@"; do
   envs=$(echo "$cfg" | tr ',' ' ')
-  line=$(env $envs timeout -k 10 200 python3 -u bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1) || { echo "$cfg FAILED" >> $out; exit 1; }
+  line=$(env $envs timeout -k 10 200 python3 -u bench.py --steps 6 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1) || { echo "$cfg FAILED" >> $out; exit 1; }
   echo "$line" | python3 -c "
 import sys,json
 j=json.loads(sys.stdin.read())
