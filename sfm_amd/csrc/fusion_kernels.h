@@ -708,6 +708,11 @@ struct ChainArgs {
 #endif
 };
 
+#if SFM_REPEAT == 5
+#define CHAIN_EPOCH_ARRIVE(i) (2 * (i) + 1)
+#else
+#define CHAIN_EPOCH_ARRIVE(i) ((i) + 1)
+#endif
 #if SFM_STAMPS
 #define SFM_CSTAMP(i)                                                                              \
     do {                                                                                           \
@@ -977,6 +982,7 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
         }
         SFM_CSTAMP(1);
         asm volatile("" ::"v"(pf_v));  // the prefetch issued before the barrier is only retired here
+        bool arrived = false;  // workgroup-uniform: this keyframe's barrier arrival is done
         const FrameDev &F = frames[f];
         const uint32_t K = F.nbr_count;
         const FrameDev *nbp = nbrpack + F.nbr_begin;
@@ -1081,6 +1087,18 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
                         if (hitk && mp) mask_store_coherent(mp + hp);
                     }
                     cnt_next[w * kWave + lane] = 0;  // all 16 chunk rows of the next round's buffer
+                    // The barrier only orders the mask stores.  After the last scatter of the keyframe the
+                    // workgroup arrives at once, and forms its fused points while the others arrive:
+                    // the fusion below is off the keyframe chain's critical path.
+                    if (f + 1 < a.f1 && c0 + R >= chunks && i0 + kChainWaves * kChainSegs >= slots &&
+                        (part == 0 || part == (uint32_t)kChainSegs)) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_s_waitcnt(0);  // my mask stores are acknowledged (write-through)
+                        __syncthreads();
+                        if (threadIdx.x == 0) chain_arrive(a.bar, G, CHAIN_EPOCH_ARRIVE(f - a.f0));
+                        arrived = true;
+                        SFM_CSTAMP(6);
+                    }
                     // ... and one wave per chunk forms the fused point and its record
                     for (int rep = 0; rep < (SFM_REPEAT == 2 ? 2 : 1); rep++)
                     if (fin) {
@@ -1160,16 +1178,13 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
         }
         SFM_CSTAMP(5);
         if (f + 1 < a.f1) {
-            // my mask stores are acknowledged (write-through) before the workgroup arrives
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-#if SFM_REPEAT == 5
-            if (threadIdx.x == 0) chain_arrive(a.bar, G, 2 * (f - a.f0) + 1);
-#else
-            if (threadIdx.x == 0) chain_arrive(a.bar, G, f - a.f0 + 1);
-#endif
-            SFM_CSTAMP(6);
+            if (!arrived) {  // a keyframe share without survivors: nothing was scattered
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+                if (threadIdx.x == 0) chain_arrive(a.bar, G, CHAIN_EPOCH_ARRIVE(f - a.f0));
+                SFM_CSTAMP(6);
+            }
             // while the others arrive: pull the next keyframe's neighbour descriptions into this
             // XCD's L2 (they are read through the scalar cache right after the barrier) ...
             {
