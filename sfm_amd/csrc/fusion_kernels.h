@@ -1169,7 +1169,11 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
                         }
                         SFM_CSTAMP(12);
                     }
-                    __syncthreads();  // LDS slots are reused by the next round / part / pass
+                    // LDS slots are reused by the next round / part / pass.  After the keyframe's last
+                    // round nothing writes LDS before the workgroup-wide sync behind the barrier wait:
+                    // the waves that have no chunk to finish go straight on to the next keyframe's
+                    // preparation while the others fuse.
+                    if (!arrived) __syncthreads();
                     SFM_CSTAMP(4);
                 }
             }
