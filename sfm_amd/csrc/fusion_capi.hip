@@ -88,7 +88,8 @@ struct sfm_fusion_ctx {
     DevBuf<unsigned long long> d_list_key, d_list_tag, d_out_key, d_out_tag, d_cand;
     DevBuf<double> d_list_xyz, d_out_xyz;
     DevBuf<uint32_t> d_list_bgr, d_out_bgr;
-    DevBuf<unsigned long long> d_fbefore, d_fafter, d_group_end;
+    DevBuf<unsigned long long> d_fbefore, d_fafter, d_group_end, d_cand_end;
+    uint64_t out_cap = 0;              // output slots of the last run (grown on kErrOutFull)
     DevBuf<uint32_t> d_qpix;           // survivor queue of the keyframe in flight
     DevBuf<double> d_qpw;
     DevBuf<unsigned int> d_qcount;     // [n_frames][kQueueShards*16] queue cursors
@@ -311,6 +312,7 @@ int build_layout(sfm_fusion_ctx *c)
     if ((rc = ensure(c, c->d_fbefore, n))) return rc;
     if ((rc = ensure(c, c->d_fafter, n))) return rc;
     if ((rc = ensure(c, c->d_group_end, (n + kGroup - 1) / kGroup * kListShards * 8))) return rc;
+    if ((rc = ensure(c, c->d_cand_end, (n + kGroup - 1) / kGroup))) return rc;
     uint64_t max_tiles = 1;
     for (auto &f : c->frames) max_tiles = std::max<uint64_t>(max_tiles, ((uint64_t)f.W * f.H + kTile - 1) / kTile);
     c->q_shard_cap = (uint32_t)((max_tiles + kQueueShards - 1) / kQueueShards * kTile);
@@ -324,7 +326,7 @@ int build_layout(sfm_fusion_ctx *c)
 }
 
 // One attempt with fixed capacities.  table_cap is a power of two.
-int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t *err_bits)
+int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t out_cap, uint32_t *err_bits)
 {
     const size_t n = c->frames.size();
     const uint64_t list_cap = shard_cap * kListShards;
@@ -335,6 +337,10 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     if ((rc = ensure(c, c->d_list_xyz, 3 * list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_bgr, list_cap))) return rc;
     if ((rc = ensure(c, c->d_cand, list_cap))) return rc;
+    if ((rc = ensure(c, c->d_out_key, out_cap))) return rc;
+    if ((rc = ensure(c, c->d_out_tag, out_cap))) return rc;
+    if ((rc = ensure(c, c->d_out_xyz, 3 * out_cap))) return rc;
+    if ((rc = ensure(c, c->d_out_bgr, out_cap))) return rc;
     const size_t n_groups = (n + kGroup - 1) / kGroup;
     while (c->gev.size() < n_groups) {
         hipEvent_t e;
@@ -396,6 +402,21 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     t.frame_before = c->d_fbefore.p;
     t.frame_after = c->d_fafter.p;
     t.cand = c->d_cand.p;
+
+    FinalizeArgs fa;
+    fa.table = c->d_table.p;
+    fa.table_mask = table_cap - 1;
+    fa.list = list;
+    fa.cand = c->d_cand.p;
+    fa.cand_end = c->d_cand_end.p;
+    fa.group = 0;
+    fa.pad = 0;
+    fa.out_cap = out_cap;
+    fa.ctr = dev_ctr(c);
+    fa.out_xyz = c->d_out_xyz.p;
+    fa.out_bgr = c->d_out_bgr.p;
+    fa.out_key = c->d_out_key.p;
+    fa.out_tag = c->d_out_tag.p;
 
     HIP_TRY(c, hipEventRecord(c->ev[1], sa));
     // the persistent chain kernel needs every keyframe's neighbour count to fit its LDS slots
@@ -499,8 +520,14 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
             t.f0 = (uint32_t)g0;
             t.f1 = (uint32_t)g1;
             t.group = (uint32_t)g;
-            if (!std::getenv("SFM_DIAG_SKIP_TABLE"))  // diagnostic only: timing of the chain without its co-runner (no output points)
+            if (!std::getenv("SFM_DIAG_SKIP_TABLE")) {  // diagnostic only: timing of the chain without its co-runner (no output points)
                 hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, kListShards), dim3(256), 0, sb, t);
+                // the group's winners are final now (later groups hold later keyframes): gather them
+                HIP_TRY(c, hipMemcpyAsync(c->d_cand_end.p + g, &dev_ctr(c)->cand_count, sizeof(unsigned long long),
+                                          hipMemcpyDeviceToDevice, sb));
+                fa.group = (uint32_t)g;
+                hipLaunchKernelGGL(finalize_kernel, dim3(c->table_wgs * kListShards), dim3(256), 0, sb, fa);
+            }
         }
     }
     HIP_TRY(c, hipGetLastError());
@@ -517,6 +544,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
     HIP_TRY(c, hipEventRecord(c->ev[2], sa));
     HIP_TRY(c, hipEventRecord(c->ev_b_done, sb));
     HIP_TRY(c, hipStreamWaitEvent(sa, c->ev_b_done, 0));
+    HIP_TRY(c, hipEventRecord(c->ev[3], sa));
     HIP_TRY(c, hipMemcpyAsync(c->h_small, c->d_small, kSmallBytes, hipMemcpyDeviceToHost, sa));
     HIP_TRY(c, hipStreamSynchronize(sa));
     uint32_t err = c->h_small->ctr.err;
@@ -526,32 +554,8 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint32_t
         if (c->h_small->cursor[s * 8] > shard_cap) err |= kErrListFull;
         n_list += std::min<uint64_t>(c->h_small->cursor[s * 8], shard_cap);
     }
-    *err_bits = err;
-    if (err) return SFM_OK;  // caller decides: grow and retry, or report
-    const uint64_t n_cand = c->h_small->ctr.cand_count;
+    *err_bits = err;  // the caller decides: grow and retry, or report
     (void)n_list;
-    if ((rc = ensure(c, c->d_out_key, n_cand))) return rc;
-    if ((rc = ensure(c, c->d_out_tag, n_cand))) return rc;
-    if ((rc = ensure(c, c->d_out_xyz, 3 * n_cand))) return rc;
-    if ((rc = ensure(c, c->d_out_bgr, n_cand))) return rc;
-    if (n_cand) {
-        FinalizeArgs fa;
-        fa.table = c->d_table.p;
-        fa.table_mask = table_cap - 1;
-        fa.list = list;
-        fa.cand = c->d_cand.p;
-        fa.ctr = dev_ctr(c);
-        fa.out_xyz = c->d_out_xyz.p;
-        fa.out_bgr = c->d_out_bgr.p;
-        fa.out_key = c->d_out_key.p;
-        fa.out_tag = c->d_out_tag.p;
-        const uint32_t bx = (uint32_t)std::min<uint64_t>((n_cand + 255) / 256, 4096);
-        hipLaunchKernelGGL(finalize_kernel, dim3(bx), dim3(256), 0, sa, fa);
-        HIP_TRY(c, hipGetLastError());
-    }
-    HIP_TRY(c, hipEventRecord(c->ev[3], sa));
-    HIP_TRY(c, hipMemcpyAsync(c->h_small, c->d_small, kSmallBytes, hipMemcpyDeviceToHost, sa));
-    HIP_TRY(c, hipStreamSynchronize(sa));
     return SFM_OK;
 }
 
@@ -663,7 +667,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_cand); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
     release(c->d_qpix); release(c->d_qpw); release(c->d_qcount); release(c->d_frames); release(c->d_bar);
-    release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_group_end);
+    release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_group_end); release(c->d_cand_end);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto &e : c->ev)
@@ -791,10 +795,13 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     uint64_t table_cap = fixed_tab ? pow2_at_least(c->prm.table_capacity)
                                    : pow2_at_least(std::max<uint64_t>(c->d_table.n,
                                                                       std::max<uint64_t>(c->total_px / 8, 1 << 16)));
+    // output slots: what the previous run ended with, else one per 16 pixels (C2 needs one per 97, the
+    // 5-mm C5 sample one per 21); the exact need is known after an overflowing run
+    uint64_t out_cap = std::max<uint64_t>(c->out_cap, std::max<uint64_t>(c->total_px / 16, 1 << 12));
     const uint64_t shard_max = c->total_px + kTile;  // every pixel live, all tiles in one shard
     for (int attempt = 0;; attempt++) {
         uint32_t err = 0;
-        if ((rc = run_once(c, table_cap, shard_cap, &err))) return rc;
+        if ((rc = run_once(c, table_cap, shard_cap, out_cap, &err))) return rc;
         const bool crowded = !err && !fixed_tab && c->h_small->ctr.table_used * 2 > table_cap;
         if (!err && !crowded) break;
         if (err & kErrBarrier) {
@@ -810,6 +817,11 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
             return fail(c, SFM_E_KEY_RANGE,
                         "a fused point's voxel index is outside the packed key range of +-(2^20-1) per axis");
         bool grown = false;
+        if (err & kErrOutFull) {
+            const uint64_t need = c->h_small->ctr.out_count;  // the counter kept counting
+            out_cap = std::max<uint64_t>(out_cap * 2, need + need / 16);
+            grown = true;
+        }
         if ((err & kErrListFull) && !fixed_list && shard_cap < shard_max) {
             uint64_t need = 0;
             for (int s = 0; s < kListShards; s++) need = std::max<uint64_t>(need, c->h_small->cursor[s * 8]);
@@ -826,6 +838,7 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
         }
     }
     c->n_out = c->h_small->ctr.out_count;
+    c->out_cap = out_cap;
     c->merged = false;
     sfm_fusion_stats &st = c->stats;
     std::memset(&st, 0, sizeof st);

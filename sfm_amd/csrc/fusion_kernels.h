@@ -55,6 +55,7 @@ constexpr uint32_t kErrTableFull = 1u;
 constexpr uint32_t kErrKeyRange = 2u;
 constexpr uint32_t kErrListFull = 4u;
 constexpr uint32_t kErrBarrier = 8u;  // fuse_chain_kernel: a device-wide barrier timed out
+constexpr uint32_t kErrOutFull = 16u;  // finalize_kernel: more winners than output slots
 
 struct FrameDev {
     double K[4];      // fx fy cx cy
@@ -1333,6 +1334,11 @@ struct FinalizeArgs {
     uint64_t table_mask;
     ListDev list;
     const unsigned long long *cand;
+    // cand_end[g] = number of candidates after group g's table kernel (device copy of the counter,
+    // taken in stream order): this launch walks [cand_end[group-1], cand_end[group])
+    const unsigned long long *cand_end;
+    uint32_t group, pad;
+    uint64_t out_cap;  // output slots; the counter keeps counting beyond (the host grows and reruns)
     Counters *ctr;
     // output (SoA, device)
     double *out_xyz;
@@ -1341,14 +1347,17 @@ struct FinalizeArgs {
     unsigned long long *out_tag;
 };
 
-// A candidate is an output point iff its tag is (still) the minimum recorded for its voxel.
+// A candidate is an output point iff its tag is the minimum recorded for its voxel.  One launch per
+// group of keyframes, right behind the group's table kernel: later groups hold later keyframes only,
+// whose tags are larger, so a group's winners are final as soon as the group is in the table.
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
 {
     const unsigned lane = lane_id();
-    const unsigned long long n = a.ctr->cand_count;
+    const unsigned long long begin = a.group ? a.cand_end[a.group - 1] : 0ull;
+    const unsigned long long n = a.cand_end[a.group];
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    const unsigned long long n_round = (n + 63) / 64 * 64;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    const unsigned long long n_round = begin + (n - begin + 63) / 64 * 64;
+    for (unsigned long long i = begin + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         bool win = false;
         unsigned long long key = 0, tag = 0, e = 0;
         if (i < n) {
@@ -1369,7 +1378,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
             const int leader = __ffsll((long long)m) - 1;
             if ((int)lane == leader) obase = atomicAdd(&a.ctr->out_count, (unsigned long long)__popcll(m));
             obase = __shfl(obase, leader);
-            if (win) {
+            if (win && obase + (unsigned)__popcll(m & lanemask_lt()) >= a.out_cap) {
+                atomicOr(&a.ctr->err, kErrOutFull);
+            } else if (win) {
                 const unsigned long long o = obase + (unsigned)__popcll(m & lanemask_lt());
                 a.out_xyz[3 * o + 0] = a.list.xyz[3 * e + 0];
                 a.out_xyz[3 * o + 1] = a.list.xyz[3 * e + 1];
