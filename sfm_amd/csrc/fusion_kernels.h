@@ -25,6 +25,9 @@
 #ifndef SFM_ABLATE
 #define SFM_ABLATE 0  // diagnostic builds only: removes one cost of fuse_chain_kernel's step B (results are wrong)
 #endif
+#ifndef SFM_BARRIER
+#define SFM_BARRIER 0  // 0: two-level counters + flag; 1: one counter everybody adds to and polls; 2: 16 counters, everybody polls all
+#endif
 #ifndef SFM_REPEAT_ABL
 #define SFM_REPEAT_ABL 0  // with SFM_REPEAT == 1: what the second (discarded) pass of step B leaves out
 #endif
@@ -738,6 +741,15 @@ __device__ __forceinline__ unsigned bar_load(const unsigned int *p)
 // thread 0 of every workgroup, once per keyframe; the caller has waited for its own stores
 __device__ __forceinline__ void chain_arrive(unsigned int *bar, unsigned G, unsigned epoch)
 {
+#if SFM_BARRIER == 1
+    (void)G; (void)epoch;
+    (void)__hip_atomic_fetch_add(bar + kBarTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+#elif SFM_BARRIER == 2
+    (void)G; (void)epoch;
+    (void)__hip_atomic_fetch_add(bar + (blockIdx.x % kBarSub) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+#endif
     const unsigned s = blockIdx.x % kBarSub;
     const unsigned members = G / kBarSub + (s < G % kBarSub ? 1u : 0u);
     const unsigned prev = __hip_atomic_fetch_add(bar + s * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -749,11 +761,26 @@ __device__ __forceinline__ void chain_arrive(unsigned int *bar, unsigned G, unsi
     }
 }
 
-__device__ __forceinline__ bool chain_wait(unsigned int *bar, unsigned epoch)
+__device__ __forceinline__ unsigned chain_progress(const unsigned int *bar, unsigned G)
+{
+#if SFM_BARRIER == 1
+    return bar_load(bar + kBarTop) / G;
+#elif SFM_BARRIER == 2
+    unsigned sum = 0;
+#pragma unroll
+    for (int i = 0; i < kBarSub; i++) sum += bar_load(bar + i * 16);
+    return sum / G;
+#else
+    (void)G;
+    return bar_load(bar + kBarFlag);
+#endif
+}
+
+__device__ __forceinline__ bool chain_wait(unsigned int *bar, unsigned epoch, unsigned G)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned spins = 0;
-    while (bar_load(bar + kBarFlag) < epoch) {
+    while (chain_progress(bar, G) < epoch) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 31u) == 0u) {
             if (bar_load(bar + kBarAbort) != 0u) return false;
@@ -967,13 +994,13 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
             // every workgroup arrived after keyframe f-1 (below); its mask stores are out
 #if SFM_REPEAT == 5
             if (threadIdx.x == 0) {  // diagnostic: a second, empty barrier behind the real one
-                bool okb = chain_wait(a.bar, 2 * (f - a.f0) - 1);
+                bool okb = chain_wait(a.bar, 2 * (f - a.f0) - 1, G);
                 chain_arrive(a.bar, G, 2 * (f - a.f0));
-                okb = okb && chain_wait(a.bar, 2 * (f - a.f0));
+                okb = okb && chain_wait(a.bar, 2 * (f - a.f0), G);
                 s_misc[1] = okb ? 1u : 0u;
             }
 #else
-            if (threadIdx.x == 0) s_misc[1] = chain_wait(a.bar, f - a.f0) ? 1u : 0u;
+            if (threadIdx.x == 0) s_misc[1] = chain_wait(a.bar, f - a.f0, G) ? 1u : 0u;
 #endif
             __syncthreads();
             if (s_misc[1] == 0u) {  // workgroup-uniform
