@@ -32,6 +32,17 @@ def test_c2_prefix_against_oracle():
     assert_same_cloud(run_gpu(frames, gp), want)
 
 
+def test_c3_prefix_against_oracle():
+    """1280x720 (C3's keyframe size): more pixels per workgroup than one pass of the persistent kernel
+    takes, and first keyframes whose share is all live (the pass is redone in parts)."""
+    seq = synth.make_sequence(6, 1280, 720, K=(913.848, 913.602, 642.941, 371.196), device="cuda")
+    frames = seq.frame_dicts()
+    op, gp = both_params(voxel_size=10.0, T_dist=500.0)
+    want = oracle.fuse(frames, op, n_threads=8)
+    assert want.key.shape[0] > 100000
+    assert_same_cloud(run_gpu(frames, gp), want)
+
+
 def test_c2_properties_at_scale():
     n = 120
     seq = synth.make_sequence(n, 640, 480, device="cuda")
