@@ -78,8 +78,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SFM_BENCH_FORCE_EXCHANGE=1: run the N>1 exchange (RCCL all-to-all + owner merge) even with one
+    # rank -- a functional check of that code path on a one-GPU box, never a measurement
+    force_exchange = os.environ.get("SFM_BENCH_FORCE_EXCHANGE") == "1"
+    if world > 1 or force_exchange:
         import torch.distributed as dist
+        if force_exchange and "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -94,7 +99,10 @@ def main():
     seq = synth.make_sequence(n_kf, W, H, K=K, device=dev, seed=20240315 + rank,
                               components=1, radius_m=0.8 * (1.0 + 0.07 * rank))
     torch.cuda.synchronize()
-    params = fusion.default_params(voxel_size=voxel, T_dist=t_dist)
+    over = {}
+    if os.environ.get("SFM_BENCH_TABLE_CAP"):   # tuning experiments only; the default run sizes automatically
+        over["table_capacity"] = int(os.environ["SFM_BENCH_TABLE_CAP"])
+    params = fusion.default_params(voxel_size=voxel, T_dist=t_dist, **over)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = fusion.FusionContext(params, local_rank, stream)
     for i in range(n_kf):
@@ -104,7 +112,7 @@ def main():
         ctx.set_neighbors(i, seq.nbrs[i])
 
     merger = None
-    if world > 1:
+    if world > 1 or force_exchange:
         from sfm_amd import dist_fusion
         # this rank's keyframes sit at [rank*n_kf, (rank+1)*n_kf) of the global processing order
         ctx.set_global_order(np.arange(n_kf, dtype=np.uint32) + rank * n_kf)
@@ -116,7 +124,7 @@ def main():
             merger.exchange_and_reduce()
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -128,14 +136,14 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_exchange:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     st = ctx.stats()
     n_points = merger.n_points if merger is not None else st["n_vox"]
-    if world > 1:
+    if world > 1 or force_exchange:
         t = torch.tensor([n_points], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
         n_points = int(t.item())
@@ -180,7 +188,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
+        "data": "synthetic (exchange forced at one rank: functional check, not a measurement)" if force_exchange else "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
         "config": {"workload": args.workload, "keyframes_per_gpu": n_kf, "width": W, "height": H,
                    "voxel_size_raw_units": voxel, "T_dist_raw_units": t_dist,
                    "depth_unit": "mm", "neighbours": "temporal +-4",
@@ -217,7 +225,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if world > 1 or force_exchange:
         dist.barrier()
         dist.destroy_process_group()
 

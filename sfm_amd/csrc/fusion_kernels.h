@@ -1454,7 +1454,9 @@ __global__ __launch_bounds__(256) void partition_count_kernel(const unsigned lon
         if (s_c[i]) atomicAdd(&counts[i], (unsigned long long)s_c[i]);
 }
 
-// cursors[p] starts at the bucket's first record index
+// cursors[p] starts at the bucket's first record index.  Bucket space is reserved per tile of 256
+// points and owner (LDS histogram, then one global atomic per tile and owner present): a global
+// atomic per point on n_parts addresses would serialise the whole cloud on them.
 __global__ __launch_bounds__(256) void partition_scatter_kernel(const unsigned long long *out_key,
                                                                 const unsigned long long *out_tag,
                                                                 const double *out_xyz, const uint32_t *out_bgr,
@@ -1462,20 +1464,38 @@ __global__ __launch_bounds__(256) void partition_scatter_kernel(const unsigned l
                                                                 const uint32_t *global_order,
                                                                 unsigned long long *cursors, Record *dst)
 {
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (unsigned long long)gridDim.x * blockDim.x) {
-        const unsigned long long key = out_key[i];
-        const unsigned long long o = atomicAdd(&cursors[part_of(key, n_parts)], 1ull);
-        Record r;
-        r.key = key;
-        const unsigned long long t = out_tag[i];  // local keyframe index -> global order
-        r.tag = ((unsigned long long)global_order[t >> 32] << 32) | (t & 0xFFFFFFFFull);
-        r.x = out_xyz[3 * i + 0];
-        r.y = out_xyz[3 * i + 1];
-        r.z = out_xyz[3 * i + 2];
-        r.bgr = out_bgr[i];
-        r.pad = 0;
-        dst[o] = r;
+    __shared__ unsigned int s_c[1024];
+    __shared__ unsigned long long s_base[1024];
+    const unsigned long long n_tiles = (n + blockDim.x - 1) / blockDim.x;
+    for (unsigned long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (uint32_t p = threadIdx.x; p < n_parts; p += blockDim.x) s_c[p] = 0;
+        __syncthreads();
+        const unsigned long long i = tile * blockDim.x + threadIdx.x;
+        const bool valid = i < n;
+        unsigned long long key = 0;
+        uint32_t part = 0, rank = 0;
+        if (valid) {
+            key = out_key[i];
+            part = part_of(key, n_parts);
+            rank = atomicAdd(&s_c[part], 1u);
+        }
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < n_parts; p += blockDim.x)
+            if (s_c[p]) s_base[p] = atomicAdd(&cursors[p], (unsigned long long)s_c[p]);
+        __syncthreads();
+        if (valid) {
+            Record r;
+            r.key = key;
+            const unsigned long long t = out_tag[i];  // local keyframe index -> global order
+            r.tag = ((unsigned long long)global_order[t >> 32] << 32) | (t & 0xFFFFFFFFull);
+            r.x = out_xyz[3 * i + 0];
+            r.y = out_xyz[3 * i + 1];
+            r.z = out_xyz[3 * i + 2];
+            r.bgr = out_bgr[i];
+            r.pad = 0;
+            dst[s_base[part] + rank] = r;
+        }
+        __syncthreads();
     }
 }
 

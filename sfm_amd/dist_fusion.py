@@ -72,10 +72,24 @@ class VoxelExchange:
         self._keep = None
 
     def exchange_and_reduce(self):
+        import os
+        import time
+        timing = os.environ.get("SFM_EXCHANGE_TIMING") == "1"   # diagnostic: host-side time of every step
+        marks = []
+
+        def mark(name):
+            if timing:
+                if isinstance(self.device, torch.device) and self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                marks.append((name, time.perf_counter()))
+
+        mark("start")
         counts = self.ctx.partition_counts(self.world)
+        mark("partition_counts")
         n_local = sum(counts)
         send = torch.empty(max(n_local, 1) * RECORD_BYTES, dtype=torch.uint8, device=self.device)
         self.ctx.export_records(send.data_ptr(), n_local * RECORD_BYTES)
+        mark("export_records")
         send_counts = torch.tensor(counts, dtype=torch.int64, device=self.device)
         recv_counts = torch.empty_like(send_counts)
         # gloo has no all-to-all on device tensors: stage through the host there (CPU tests and
@@ -86,6 +100,7 @@ class VoxelExchange:
             recv_counts = recv_counts.cpu()
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         rc = [int(x) for x in recv_counts.tolist()]
+        mark("all_to_all counts")
         n_recv = sum(rc)
         recv = torch.empty(max(n_recv, 1) * RECORD_BYTES, dtype=torch.uint8, device=self.device)
         in_splits = [c * RECORD_BYTES for c in counts]
@@ -100,7 +115,12 @@ class VoxelExchange:
                                    out_splits, in_splits, group=self.group)
         if recv.is_cuda:
             torch.cuda.current_stream(recv.device).synchronize()
+        mark("all_to_all records")
         self.ctx.merge(recv.data_ptr(), n_recv)
+        mark("merge")
+        if timing and self.rank == 0:
+            print("exchange timing (ms): " + ", ".join(
+                "%s %.3f" % (marks[i][0], (marks[i][1] - marks[i - 1][1]) * 1e3) for i in range(1, len(marks))), flush=True)
         self._keep = (send, recv)
         self.n_points = self.ctx.num_points()
         self.sent_records, self.recv_records = n_local, n_recv
