@@ -1377,44 +1377,79 @@ struct FinalizeArgs {
 // A candidate is an output point iff its tag is the minimum recorded for its voxel.  One launch per
 // group of keyframes, right behind the group's table kernel: later groups hold later keyframes only,
 // whose tags are larger, so a group's winners are final as soon as the group is in the table.
+// Output space for a 256-thread block's winners: kFinItems candidates per thread, one global
+// atomic per block and tile (one per wave serialises on the counter's address: 25 k atomics at
+// ~90 per microsecond for a C2 cloud).  Every thread of the block must call it.
+constexpr int kFinItems = 4;
+__device__ __forceinline__ void block_reserve(const bool (&win)[kFinItems], unsigned long long *counter,
+                                              unsigned int *s_w, unsigned long long *s_base,
+                                              unsigned long long (&off)[kFinItems])
+{
+    const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
+    unsigned run = 0, loc[kFinItems];
+#pragma unroll
+    for (int j = 0; j < kFinItems; j++) {
+        const unsigned long long m = __ballot(win[j]);
+        loc[j] = run + (unsigned)__popcll(m & lanemask_lt());
+        run += (unsigned)__popcll(m);
+    }
+    if (lane == 0) s_w[wave] = run;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        *s_base = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long base = *s_base;
+    for (unsigned w = 0; w < wave; w++) base += s_w[w];
+#pragma unroll
+    for (int j = 0; j < kFinItems; j++) off[j] = base + loc[j];
+    __syncthreads();  // s_w and s_base are reused by the next tile
+}
+
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
 {
-    const unsigned lane = lane_id();
+    __shared__ unsigned int s_w[4];
+    __shared__ unsigned long long s_base;
     const unsigned long long begin = a.group ? a.cand_end[a.group - 1] : 0ull;
     const unsigned long long n = a.cand_end[a.group];
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    const unsigned long long n_round = begin + (n - begin + 63) / 64 * 64;
-    for (unsigned long long i = begin + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        bool win = false;
-        unsigned long long key = 0, tag = 0, e = 0;
-        if (i < n) {
-            e = a.cand[i];
-            tag = a.list.tag[e];
-            key = a.list.key[e];
-            uint64_t h = mix64(key) & a.table_mask;
-            for (;;) {
-                const unsigned long long cur = a.table[h].key;
-                if (cur == key) { win = a.table[h].tag == tag; break; }
-                if (cur == kEmpty) break;  // cannot happen: every candidate's key was inserted
-                h = (h + 1) & a.table_mask;
+    const unsigned long long tile_sz = 256ull * kFinItems;
+    const unsigned long long tiles = (n - begin + tile_sz - 1) / tile_sz;
+    for (unsigned long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        bool win[kFinItems];
+        unsigned long long key[kFinItems], tag[kFinItems], e[kFinItems], off[kFinItems];
+#pragma unroll
+        for (int j = 0; j < kFinItems; j++) {
+            const unsigned long long i = begin + tile * tile_sz + (unsigned)j * 256u + threadIdx.x;
+            win[j] = false;
+            key[j] = tag[j] = e[j] = 0;
+            if (i < n) {
+                e[j] = a.cand[i];
+                tag[j] = a.list.tag[e[j]];
+                key[j] = a.list.key[e[j]];
+                uint64_t h = mix64(key[j]) & a.table_mask;
+                for (;;) {
+                    const unsigned long long cur = a.table[h].key;
+                    if (cur == key[j]) { win[j] = a.table[h].tag == tag[j]; break; }
+                    if (cur == kEmpty) break;  // cannot happen: every candidate's key was inserted
+                    h = (h + 1) & a.table_mask;
+                }
             }
         }
-        const unsigned long long m = __ballot(win);
-        if (m != 0) {
-            unsigned long long obase = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if ((int)lane == leader) obase = atomicAdd(&a.ctr->out_count, (unsigned long long)__popcll(m));
-            obase = __shfl(obase, leader);
-            if (win && obase + (unsigned)__popcll(m & lanemask_lt()) >= a.out_cap) {
+        block_reserve(win, &a.ctr->out_count, s_w, &s_base, off);
+#pragma unroll
+        for (int j = 0; j < kFinItems; j++) {
+            if (!win[j]) continue;
+            const unsigned long long o = off[j];
+            if (o >= a.out_cap) {
                 atomicOr(&a.ctr->err, kErrOutFull);
-            } else if (win) {
-                const unsigned long long o = obase + (unsigned)__popcll(m & lanemask_lt());
-                a.out_xyz[3 * o + 0] = a.list.xyz[3 * e + 0];
-                a.out_xyz[3 * o + 1] = a.list.xyz[3 * e + 1];
-                a.out_xyz[3 * o + 2] = a.list.xyz[3 * e + 2];
-                a.out_bgr[o] = a.list.bgr[e];
-                a.out_key[o] = key;
-                a.out_tag[o] = tag;
+            } else {
+                a.out_xyz[3 * o + 0] = a.list.xyz[3 * e[j] + 0];
+                a.out_xyz[3 * o + 1] = a.list.xyz[3 * e[j] + 1];
+                a.out_xyz[3 * o + 2] = a.list.xyz[3 * e[j] + 2];
+                a.out_bgr[o] = a.list.bgr[e[j]];
+                a.out_key[o] = key[j];
+                a.out_tag[o] = tag[j];
             }
         }
     }
@@ -1530,38 +1565,40 @@ __global__ __launch_bounds__(256) void merge_finalize_kernel(const Record *rec, 
                                                              double *out_xyz, uint32_t *out_bgr,
                                                              unsigned long long *out_key, unsigned long long *out_tag)
 {
-    const unsigned lane = lane_id();
-    const unsigned long long n_round = (n + 63) / 64 * 64;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round;
-         i += (unsigned long long)gridDim.x * blockDim.x) {
-        bool win = false;
-        Record r;
-        r.key = 0; r.tag = 0; r.x = r.y = r.z = 0; r.bgr = 0; r.pad = 0;
-        if (i < n) {
-            r = rec[i];
-            uint64_t h = mix64(r.key) & table_mask;
-            for (;;) {
-                const unsigned long long cur = table[h].key;
-                if (cur == r.key) { win = table[h].tag == r.tag; break; }
-                if (cur == kEmpty) break;
-                h = (h + 1) & table_mask;
+    __shared__ unsigned int s_w[4];
+    __shared__ unsigned long long s_base;
+    const unsigned long long tile_sz = 256ull * kFinItems;
+    const unsigned long long tiles = (n + tile_sz - 1) / tile_sz;
+    for (unsigned long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        bool win[kFinItems];
+        unsigned long long off[kFinItems];
+#pragma unroll
+        for (int j = 0; j < kFinItems; j++) {
+            const unsigned long long i = tile * tile_sz + (unsigned)j * 256u + threadIdx.x;
+            win[j] = false;
+            if (i < n) {
+                const unsigned long long key = rec[i].key, tag = rec[i].tag;
+                uint64_t h = mix64(key) & table_mask;
+                for (;;) {
+                    const unsigned long long cur = table[h].key;
+                    if (cur == key) { win[j] = table[h].tag == tag; break; }
+                    if (cur == kEmpty) break;
+                    h = (h + 1) & table_mask;
+                }
             }
         }
-        const unsigned long long m = __ballot(win);
-        if (m != 0) {
-            unsigned long long obase = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if ((int)lane == leader) obase = atomicAdd(&ctr->out_count, (unsigned long long)__popcll(m));
-            obase = __shfl(obase, leader);
-            if (win) {
-                const unsigned long long o = obase + (unsigned)__popcll(m & lanemask_lt());
-                out_xyz[3 * o + 0] = r.x;
-                out_xyz[3 * o + 1] = r.y;
-                out_xyz[3 * o + 2] = r.z;
-                out_bgr[o] = r.bgr;
-                out_key[o] = r.key;
-                out_tag[o] = r.tag;
-            }
+        block_reserve(win, &ctr->out_count, s_w, &s_base, off);
+#pragma unroll
+        for (int j = 0; j < kFinItems; j++) {
+            if (!win[j]) continue;
+            const Record r = rec[tile * tile_sz + (unsigned)j * 256u + threadIdx.x];
+            const unsigned long long o = off[j];
+            out_xyz[3 * o + 0] = r.x;
+            out_xyz[3 * o + 1] = r.y;
+            out_xyz[3 * o + 2] = r.z;
+            out_bgr[o] = r.bgr;
+            out_key[o] = r.key;
+            out_tag[o] = r.tag;
         }
     }
 }
