@@ -6,8 +6,13 @@ cd "$(dirname "$0")"
 mkdir -p sfm_amd/lib build
 # -amdgpu-atomic-optimizer-strategy=None: that pass rewrites a one-lane atomic into atomic + readfirstlane and so
 # forces a wait for the atomic's round trip right behind it; the kernels aggregate their atomics themselves
-hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None -fPIC -shared -std=c++17 -Wall \
-  -save-temps=obj sfm_amd/csrc/fusion_capi.hip -o build/libsfm_fusion.so "$@"
+hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None -fPIC -std=c++17 -Wall \
+  -save-temps=obj -c sfm_amd/csrc/fusion_capi.hip -o build/fusion_capi.o "$@"
+# the output cloud's sort (rocPRIM) in its own translation unit; rebuilt only when it changes
+if [ ! -f build/cloud_sort.o ] || [ sfm_amd/csrc/cloud_sort.hip -nt build/cloud_sort.o ]; then
+  hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -c sfm_amd/csrc/cloud_sort.hip -o build/cloud_sort.o
+fi
+hipcc --offload-arch=gfx950 -fPIC -shared build/fusion_capi.o build/cloud_sort.o -o build/libsfm_fusion.so
 cp build/libsfm_fusion.so sfm_amd/lib/libsfm_fusion.so
 # C++ facade example (host-only code over the C ABI); run by tests/test_gpu_cpp_facade.py
 g++ -std=c++17 -O2 -Wall sfm_amd/cpp/facade_example.cpp -Lsfm_amd/lib -lsfm_fusion \

@@ -24,6 +24,13 @@
 
 using namespace sfm;
 
+namespace sfm {
+// cloud_sort.hip (rocPRIM radix sort; tmp == nullptr: size query)
+hipError_t sort_keys_with_index(void *tmp, size_t &tmp_bytes, const unsigned long long *keys_in,
+                                unsigned long long *keys_out, const uint32_t *idx_in, uint32_t *idx_out, size_t n,
+                                hipStream_t stream);
+}  // namespace sfm
+
 namespace {
 
 struct HostFrame {
@@ -64,6 +71,24 @@ struct sfm_fusion_ctx {
     bool own_stream = false;
     std::vector<HostFrame> frames;
     bool layout_dirty = true;
+    // keyframe images live in a few large device chunks (one hipMalloc per keyframe image cost more
+    // than its copy); host images are packed into one of two pinned staging buffers and copied on
+    // the upload stream while the caller prepares the next keyframe
+    struct Arena {
+        std::vector<void *> chunks;
+        unsigned char *cur = nullptr;
+        size_t left = 0, next_chunk = 8u << 20;
+    } arena;
+    struct Stage {
+        unsigned char *h = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;
+        bool busy = false;
+    } stage[2];
+    int stage_i = 0;
+    hipStream_t stream_up = nullptr;
+    hipEvent_t ev_up = nullptr;
+    bool up_pending = false;
 
     DevBuf<double> d_tables;         // x/y/covariance lookup tables
     DevBuf<FrameDev> d_nbrpack;      // per keyframe: a FrameDev copy of each filtered neighbour
@@ -114,6 +139,12 @@ struct sfm_fusion_ctx {
     DevBuf<uint32_t> d_gorder;
     bool merged = false;                // cloud tags already carry global orders
     DevBuf<unsigned long long> d_part; // [2 * n_parts] bucket counts, then scatter cursors
+    // sfm_fusion_read_points: sorted keys, permutation (2n), sort scratch, the cloud in the caller's layout
+    DevBuf<unsigned long long> d_rd_keys, d_rd_key3, d_rd_tag;
+    DevBuf<uint32_t> d_rd_perm;
+    DevBuf<unsigned char> d_rd_tmp;
+    DevBuf<double> d_rd_xyz;
+    DevBuf<int32_t> d_rd_bgr;
     std::vector<uint64_t> part_counts; // last sfm_fusion_partition_counts result
     uint64_t total_px = 0;
     uint64_t n_out = 0;
@@ -150,6 +181,44 @@ int fail(sfm_fusion_ctx *c, int code, const std::string &msg)
             return fail((c), e_ == hipErrorOutOfMemory ? SFM_E_NOMEM : SFM_E_HIP,            \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
+
+int arena_alloc(sfm_fusion_ctx *c, size_t bytes, void **out)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto &a = c->arena;
+    if (a.left < bytes) {
+        size_t chunk = std::max(bytes, a.next_chunk);
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, chunk);
+        if (e != hipSuccess && chunk > bytes) {  // a large chunk may not fit where the image alone does
+            (void)hipGetLastError();
+            chunk = bytes;
+            e = hipMalloc(&p, chunk);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, SFM_E_NOMEM, "hipMalloc keyframe images");
+        }
+        a.chunks.push_back(p);
+        a.cur = (unsigned char *)p;
+        a.left = chunk;
+        a.next_chunk = std::min<size_t>(a.next_chunk * 2, (size_t)512 << 20);
+    }
+    *out = a.cur;
+    a.cur += bytes;
+    a.left -= bytes;
+    return SFM_OK;
+}
+
+// rows of `row` bytes, `stride` apart -> contiguous
+void pack_rows(unsigned char *dst, const void *src, size_t row, size_t stride, int32_t H)
+{
+    if (stride == row) {
+        std::memcpy(dst, src, row * (size_t)H);
+        return;
+    }
+    for (int32_t y = 0; y < H; y++) std::memcpy(dst + row * (size_t)y, (const unsigned char *)src + stride * (size_t)y, row);
+}
 
 template <typename T>
 int ensure(sfm_fusion_ctx *c, DevBuf<T> &b, uint64_t n)
@@ -640,6 +709,9 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
         c->own_stream = ok;
     }
     ok = ok && hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) == hipSuccess;
+    for (auto &st : c->stage) ok = ok && hipEventCreateWithFlags(&st.ev, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&c->d_small, kSmallBytes) == hipSuccess;
     ok = ok && hipHostMalloc(&c->h_small, kSmallBytes, hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
@@ -659,10 +731,16 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
-    for (auto &f : c->frames) {
-        if (f.d_depth) (void)hipFree(f.d_depth);
-        if (f.d_bgr) (void)hipFree(f.d_bgr);
+    if (c->stream_up) (void)hipStreamSynchronize(c->stream_up);
+    for (void *p : c->arena.chunks) (void)hipFree(p);
+    for (auto &st : c->stage) {
+        if (st.h) (void)hipHostFree(st.h);
+        if (st.ev) (void)hipEventDestroy(st.ev);
     }
+    if (c->ev_up) (void)hipEventDestroy(c->ev_up);
+    if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
+    release(c->d_rd_keys); release(c->d_rd_key3); release(c->d_rd_tag); release(c->d_rd_perm); release(c->d_rd_tmp);
+    release(c->d_rd_xyz); release(c->d_rd_bgr);
     release(c->d_part); release(c->d_gorder); release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
     release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_cand); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
@@ -705,19 +783,36 @@ int sfm_fusion_add_keyframe(sfm_fusion_ctx *c, uint32_t order_idx, int32_t W, in
     std::memcpy(f.Tkw, T_kw, sizeof f.Tkw);
     if (px) {
         // +8 bytes of slack: the kernel reads depth as ushort4 / colour per byte
-        HIP_TRY(c, hipMalloc(&f.d_depth, px * 2 + 8));
-        hipError_t e = hipMalloc(&f.d_bgr, px * 3 + 8);
-        if (e != hipSuccess) {
-            (void)hipFree(f.d_depth);
-            return fail(c, SFM_E_NOMEM, "hipMalloc colour");
-        }
-        const hipMemcpyKind kind = mem_kind == SFM_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-        hipError_t e1 = hipMemcpy2D(f.d_depth, 2ull * W, depth, depth_stride, 2ull * W, H, kind);
-        hipError_t e2 = hipMemcpy2D(f.d_bgr, 3ull * W, bgr, bgr_stride, 3ull * W, H, kind);
-        if (e1 != hipSuccess || e2 != hipSuccess) {
-            (void)hipFree(f.d_depth);
-            (void)hipFree(f.d_bgr);
-            return fail(c, SFM_E_HIP, std::string("hipMemcpy2D: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        int rc;
+        if ((rc = arena_alloc(c, px * 2 + 8, (void **)&f.d_depth))) return rc;
+        if ((rc = arena_alloc(c, px * 3 + 8, (void **)&f.d_bgr))) return rc;
+        if (mem_kind == SFM_MEM_HOST) {
+            auto &st = c->stage[c->stage_i];
+            c->stage_i ^= 1;
+            if (st.busy) {
+                HIP_TRY(c, hipEventSynchronize(st.ev));
+                st.busy = false;
+            }
+            if (st.cap < px * 5) {
+                if (st.h) HIP_TRY(c, hipHostFree(st.h));
+                st.h = nullptr;
+                st.cap = 0;
+                HIP_TRY(c, hipHostMalloc((void **)&st.h, px * 5, hipHostMallocDefault));
+                st.cap = px * 5;
+            }
+            // the caller's buffers are free again when this returns
+            pack_rows(st.h, depth, 2ull * W, depth_stride, H);
+            pack_rows(st.h + px * 2, bgr, 3ull * W, bgr_stride, H);
+            HIP_TRY(c, hipMemcpyAsync(f.d_depth, st.h, px * 2, hipMemcpyHostToDevice, c->stream_up));
+            HIP_TRY(c, hipMemcpyAsync(f.d_bgr, st.h + px * 2, px * 3, hipMemcpyHostToDevice, c->stream_up));
+            HIP_TRY(c, hipEventRecord(st.ev, c->stream_up));
+            st.busy = true;
+            c->up_pending = true;
+        } else {
+            hipError_t e1 = hipMemcpy2D(f.d_depth, 2ull * W, depth, depth_stride, 2ull * W, H, hipMemcpyDeviceToDevice);
+            hipError_t e2 = hipMemcpy2D(f.d_bgr, 3ull * W, bgr, bgr_stride, 3ull * W, H, hipMemcpyDeviceToDevice);
+            if (e1 != hipSuccess || e2 != hipSuccess)
+                return fail(c, SFM_E_HIP, std::string("hipMemcpy2D: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
         }
     }
     c->frames.push_back(std::move(f));
@@ -784,6 +879,11 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
             if (j == i) return fail(c, SFM_E_INVALID, "a keyframe cannot be its own neighbour");
         }
     int rc;
+    if (c->up_pending) {  // the images still in flight on the upload stream
+        HIP_TRY(c, hipEventRecord(c->ev_up, c->stream_up));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up, 0));
+        c->up_pending = false;
+    }
     if (c->layout_dirty && (rc = build_layout(c))) return rc;
     c->have_result = false;
     const bool fixed_tab = c->prm.table_capacity != 0, fixed_list = c->prm.max_points != 0;
@@ -1006,13 +1106,6 @@ int sfm_fusion_num_points(sfm_fusion_ctx *c, uint64_t *n)
     return SFM_OK;
 }
 
-static inline uint64_t unpack_axis(uint64_t code)
-{
-    if (code == 0x100000ull) return 0x8000000000000000ull;
-    int64_t k = (int64_t)(code << 43) >> 43;  // sign-extend 21 bits
-    return (uint64_t)k;
-}
-
 int sfm_fusion_read_points(sfm_fusion_ctx *c, double *xyz, int32_t *bgr, uint64_t *key, uint64_t *tag)
 {
     if (!c) return SFM_E_INVALID;
@@ -1020,38 +1113,43 @@ int sfm_fusion_read_points(sfm_fusion_ctx *c, double *xyz, int32_t *bgr, uint64_
     HIP_TRY(c, hipSetDevice(c->device));
     const uint64_t n = c->n_out;
     if (n == 0) return SFM_OK;
-    std::vector<unsigned long long> hk(n), ht(n);
-    std::vector<double> hx(3 * n);
-    std::vector<uint32_t> hc(n);
-    HIP_TRY(c, hipMemcpy(hk.data(), c->d_out_key.p, n * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(ht.data(), c->d_out_tag.p, n * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(hx.data(), c->d_out_xyz.p, n * 24, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(hc.data(), c->d_out_bgr.p, n * 4, hipMemcpyDeviceToHost));
-    std::vector<uint64_t> k0(n), k1(n), k2(n);
-    for (uint64_t i = 0; i < n; i++) {
-        k0[i] = unpack_axis((hk[i] >> 42) & 0x1FFFFF);
-        k1[i] = unpack_axis((hk[i] >> 21) & 0x1FFFFF);
-        k2[i] = unpack_axis(hk[i] & 0x1FFFFF);
+    if (n > 0xFFFFFFFFull) return fail(c, SFM_E_UNSUPPORTED, "more than 2^32 output points");
+    // sort by packed key and bring the cloud into the caller's layout on the device; the host only copies
+    int rc;
+    if ((rc = ensure(c, c->d_rd_keys, n))) return rc;
+    if ((rc = ensure(c, c->d_rd_perm, 2 * n))) return rc;
+    if ((rc = ensure(c, c->d_rd_xyz, 3 * n))) return rc;
+    if ((rc = ensure(c, c->d_rd_bgr, 3 * n))) return rc;
+    if ((rc = ensure(c, c->d_rd_key3, 3 * n))) return rc;
+    if ((rc = ensure(c, c->d_rd_tag, n))) return rc;
+    hipStream_t s = c->stream;
+    const bool remap = !c->merged && !c->global_order.empty() && c->global_order.size() == c->frames.size();
+    if (remap) {
+        if ((rc = ensure(c, c->d_gorder, c->global_order.size()))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->d_gorder.p, c->global_order.data(), c->global_order.size() * sizeof(uint32_t),
+                                  hipMemcpyHostToDevice, s));
     }
-    std::vector<uint64_t> order(n);
-    std::iota(order.begin(), order.end(), (uint64_t)0);
-    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
-        if (k0[a] != k0[b]) return k0[a] < k0[b];
-        if (k1[a] != k1[b]) return k1[a] < k1[b];
-        return k2[a] < k2[b];
-    });
-    for (uint64_t o = 0; o < n; o++) {
-        const uint64_t i = order[o];
-        if (xyz) { xyz[3 * o] = hx[3 * i]; xyz[3 * o + 1] = hx[3 * i + 1]; xyz[3 * o + 2] = hx[3 * i + 2]; }
-        if (bgr) { bgr[3 * o] = hc[i] & 255; bgr[3 * o + 1] = (hc[i] >> 8) & 255; bgr[3 * o + 2] = (hc[i] >> 16) & 255; }
-        if (key) { key[3 * o] = k0[i]; key[3 * o + 1] = k1[i]; key[3 * o + 2] = k2[i]; }
-        if (tag) {
-            uint64_t t = ht[i];
-            if (!c->merged && c->global_order.size() == c->frames.size() && (t >> 32) < c->global_order.size())
-                t = ((uint64_t)c->global_order[t >> 32] << 32) | (t & 0xFFFFFFFFull);
-            tag[o] = t;
-        }
-    }
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(iota_kernel, dim3(blocks), dim3(256), 0, s, c->d_rd_perm.p, (unsigned long long)n);
+    HIP_TRY(c, hipGetLastError());
+    size_t tmp_bytes = 0;
+    HIP_TRY(c, sort_keys_with_index(nullptr, tmp_bytes, c->d_out_key.p, c->d_rd_keys.p, c->d_rd_perm.p,
+                                    c->d_rd_perm.p + n, n, s));
+    if ((rc = ensure(c, c->d_rd_tmp, tmp_bytes))) return rc;
+    HIP_TRY(c, sort_keys_with_index(c->d_rd_tmp.p, tmp_bytes, c->d_out_key.p, c->d_rd_keys.p, c->d_rd_perm.p,
+                                    c->d_rd_perm.p + n, n, s));
+    hipLaunchKernelGGL(cloud_gather_kernel, dim3(blocks), dim3(256), 0, s, (const uint32_t *)(c->d_rd_perm.p + n),
+                       (unsigned long long)n, (const unsigned long long *)c->d_out_key.p,
+                       (const unsigned long long *)c->d_out_tag.p, (const double *)c->d_out_xyz.p,
+                       (const uint32_t *)c->d_out_bgr.p, (const uint32_t *)c->d_gorder.p,
+                       remap ? (uint32_t)c->global_order.size() : 0u, c->d_rd_xyz.p, c->d_rd_bgr.p, c->d_rd_key3.p,
+                       c->d_rd_tag.p);
+    HIP_TRY(c, hipGetLastError());
+    if (xyz) HIP_TRY(c, hipMemcpyAsync(xyz, c->d_rd_xyz.p, n * 24, hipMemcpyDeviceToHost, s));
+    if (bgr) HIP_TRY(c, hipMemcpyAsync(bgr, c->d_rd_bgr.p, n * 12, hipMemcpyDeviceToHost, s));
+    if (key) HIP_TRY(c, hipMemcpyAsync(key, c->d_rd_key3.p, n * 24, hipMemcpyDeviceToHost, s));
+    if (tag) HIP_TRY(c, hipMemcpyAsync(tag, c->d_rd_tag.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
     return SFM_OK;
 }
 

@@ -1603,4 +1603,49 @@ __global__ __launch_bounds__(256) void merge_finalize_kernel(const Record *rec, 
     }
 }
 
+// ---- read-out: the cloud in voxel-key order, in the layout sfm_fusion_read_points hands out ----
+
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t *idx, unsigned long long n)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        idx[i] = (uint32_t)i;
+}
+
+// 21-bit axis code -> the reference's size_t key component (two's complement; 0x100000 = x86 indefinite)
+__device__ __forceinline__ unsigned long long unpack_axis_dev(unsigned long long code)
+{
+    if (code == 0x100000ull) return 0x8000000000000000ull;
+    return (unsigned long long)((long long)(code << 43) >> 43);
+}
+
+// perm: positions in ascending packed-key order, which is the lexicographic order of the three
+// unsigned components (non-negative indices, then the indefinite value, then negative ones, per axis)
+__global__ __launch_bounds__(256) void cloud_gather_kernel(const uint32_t *perm, unsigned long long n,
+                                                           const unsigned long long *out_key,
+                                                           const unsigned long long *out_tag, const double *out_xyz,
+                                                           const uint32_t *out_bgr, const uint32_t *global_order,
+                                                           uint32_t n_global_order, double *dst_xyz, int32_t *dst_bgr,
+                                                           unsigned long long *dst_key, unsigned long long *dst_tag)
+{
+    for (unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; o < n;
+         o += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t i = perm[o];
+        dst_xyz[3 * o + 0] = out_xyz[3ull * i + 0];
+        dst_xyz[3 * o + 1] = out_xyz[3ull * i + 1];
+        dst_xyz[3 * o + 2] = out_xyz[3ull * i + 2];
+        const uint32_t c = out_bgr[i];
+        dst_bgr[3 * o + 0] = (int32_t)(c & 255);
+        dst_bgr[3 * o + 1] = (int32_t)((c >> 8) & 255);
+        dst_bgr[3 * o + 2] = (int32_t)((c >> 16) & 255);
+        const unsigned long long k = out_key[i];
+        dst_key[3 * o + 0] = unpack_axis_dev((k >> 42) & 0x1FFFFF);
+        dst_key[3 * o + 1] = unpack_axis_dev((k >> 21) & 0x1FFFFF);
+        dst_key[3 * o + 2] = unpack_axis_dev(k & 0x1FFFFF);
+        unsigned long long t = out_tag[i];
+        if ((t >> 32) < n_global_order) t = ((unsigned long long)global_order[t >> 32] << 32) | (t & 0xFFFFFFFFull);
+        dst_tag[o] = t;
+    }
+}
+
 }  // namespace sfm
