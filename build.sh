@@ -15,12 +15,12 @@ fi
 hipcc --offload-arch=gfx950 -fPIC -shared build/fusion_capi.o build/cloud_sort.o -o build/libsfm_fusion.so
 cp build/libsfm_fusion.so sfm_amd/lib/libsfm_fusion.so
 # C++ facade example (host-only code over the C ABI); run by tests/test_gpu_cpp_facade.py
-g++ -std=c++17 -O2 -Wall sfm_amd/cpp/facade_example.cpp -Lsfm_amd/lib -lsfm_fusion \
+g++ -std=c++17 -O2 -Wall -pthread sfm_amd/cpp/facade_example.cpp -Lsfm_amd/lib -lsfm_fusion \
   -Wl,-rpath,'$ORIGIN/../lib' -o sfm_amd/cpp/facade_example
-g++ -std=c++17 -O2 -Wall sfm_amd/cpp/replay_reconstruct.cpp -Lsfm_amd/lib -lsfm_fusion \
+g++ -std=c++17 -O2 -Wall -pthread sfm_amd/cpp/replay_reconstruct.cpp -Lsfm_amd/lib -lsfm_fusion \
   -Wl,-rpath,'$ORIGIN/../lib' -o sfm_amd/cpp/replay_reconstruct
 # host-only formatter probe used by tests/test_writer_parity.py
-g++ -std=c++17 -O2 -Wall tests/cpp/writer_probe.cpp -o build/writer_probe
+g++ -std=c++17 -O2 -Wall -pthread tests/cpp/writer_probe.cpp -o build/writer_probe
 g++ -std=c++17 -O2 -Wall tests/cpp/recording_probe.cpp -lz -o build/recording_probe
 # fuse_chain_kernel must leave VGPRs for a co-resident table-kernel wave (see the kernel's comment)
 nv=$(grep -E "fuse_chain_kernel.*\.num_vgpr," build/fusion_capi-hip-amdgcn-amd-amdhsa-gfx950.s | head -1 | sed 's/.*num_vgpr, *//')

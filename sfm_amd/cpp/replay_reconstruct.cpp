@@ -1,10 +1,11 @@
 // replay_reconstruct.cpp -- the fusion half of the reference's `reconstruct` executable
 // (src/reconstruct.cpp:69-73) over a keyframe replay dump:
-//     replay_reconstruct <dump.sfmr> <out> [--ply] [--voxel-size V] [--t-dist T] [--rewrite <copy.sfmr>]
+//     replay_reconstruct <dump.sfmr> <out> [--ply] [--voxel-size V] [--t-dist T] [--rewrite <copy.sfmr>] [--timing]
 // Host-only C++ over the C ABI (libsfm_fusion.so); --rewrite re-exports the dump through the C++
 // writer (used by the tests to check the two implementations of the format against each other).
 #include "replay.hpp"
 
+#include <chrono>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -16,8 +17,14 @@ int main(int argc, char **argv)
         return 2;
     }
     try {
+        using clk = std::chrono::steady_clock;
+        const auto ms = [](clk::time_point a, clk::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        const auto t0 = clk::now();
         sfm_amd::Replay replay(argv[1]);
-        bool ply = false;
+        const auto t1 = clk::now();
+        bool ply = false, timing = false;
         std::string rewrite;
         sfm_amd::DenseReconstruction dense{replay.map};
         for (int i = 3; i < argc; i++) {
@@ -26,13 +33,22 @@ int main(int argc, char **argv)
             else if (a == "--voxel-size" && i + 1 < argc) dense.params().voxel_size = std::atof(argv[++i]);
             else if (a == "--t-dist" && i + 1 < argc) dense.params().T_dist = std::atof(argv[++i]);
             else if (a == "--rewrite" && i + 1 < argc) rewrite = argv[++i];
+            else if (a == "--timing") timing = true;
             else { std::cerr << "unknown option " << a << "\n"; return 2; }
         }
         if (!rewrite.empty()) sfm_amd::write_replay(rewrite, replay.map);
         std::ofstream out(argv[2], std::ios::binary);
         if (!out) throw std::runtime_error(std::string("cannot create ") + argv[2]);
-        if (ply) dense.reconstruct_ply(out);
-        else dense.reconstruct(out);
+        const auto t2 = clk::now();
+        const sfm_amd::Cloud cloud = dense.fuse();
+        const auto t3 = clk::now();
+        if (ply) sfm_amd::write_ply_binary(out, cloud.xyz.data(), cloud.bgr.data(), cloud.size());
+        else sfm_amd::write_text_fast(out, cloud.xyz.data(), cloud.bgr.data(), cloud.size());
+        out.flush();
+        const auto t4 = clk::now();
+        if (timing)
+            std::cout << "timing (ms): open dump " << ms(t0, t1) << ", upload + fuse + read back " << ms(t2, t3)
+                      << " (device run " << dense.stats().last_run_ms << "), write " << ms(t3, t4) << "\n";
         std::cout << dense.stats().n_frames << " keyframes selected, " << dense.stats().n_vox << " points\n";
     } catch (const std::exception &e) {
         std::cerr << "replay_reconstruct: " << e.what() << "\n";

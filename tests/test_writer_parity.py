@@ -22,7 +22,7 @@ def probe():
     hdr = os.path.join(ROOT, "sfm_amd", "cpp", "cloud_writer.hpp")
     if not os.path.exists(PROBE) or os.path.getmtime(PROBE) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         os.makedirs(os.path.dirname(PROBE), exist_ok=True)
-        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", src, "-o", PROBE], check=True)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", src, "-o", PROBE], check=True)
     return PROBE
 
 
@@ -84,6 +84,14 @@ def test_text_writers_agree_byte_for_byte(probe, tmp_path):
     buf = io.StringIO()
     fusion.write_sparse_csv(buf, xyz, bgr)
     assert buf.getvalue().encode("ascii") == csv
+
+
+def test_threaded_fast_writer_keeps_the_order(probe, tmp_path):
+    xyz, bgr = _cloud(200_000)                       # several 64-Ki blocks: formatted in parallel, written in order
+    path = _dump(tmp_path, xyz, bgr)
+    ref = subprocess.run([probe, "text", path], capture_output=True, check=True).stdout
+    fast = subprocess.run([probe, "fast", path], capture_output=True, check=True).stdout
+    assert fast == ref and ref.count(b"\n") == 200_000
 
 
 def test_ply_writers_agree_and_round_trip(probe, tmp_path):
