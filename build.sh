@@ -25,3 +25,9 @@ g++ -std=c++17 -O2 -Wall tests/cpp/recording_probe.cpp -lz -o build/recording_pr
 # fuse_chain_kernel must leave VGPRs for a co-resident table-kernel wave (see the kernel's comment)
 nv=$(grep -E "fuse_chain_kernel.*\.num_vgpr," build/fusion_capi-hip-amdgcn-amd-amdhsa-gfx950.s | head -1 | sed 's/.*num_vgpr, *//')
 if [ -n "$nv" ] && [ "$nv" -gt 120 ]; then echo "build.sh: fuse_chain_kernel uses $nv VGPRs (> 120)" >&2; exit 1; fi
+# ... and the kernels that run beside it on stream B must fit into what it leaves: 512 - 4 * 120 = 32 VGPRs per SIMD
+# (a table kernel with 43 VGPRs waited for whole chain launches to end: 8.1 -> 11 ms per C2 run)
+for k in table_group_kernel finalize_kernel; do
+  nv=$(grep -E "sfm[0-9]+${k}E.*\.num_vgpr," build/fusion_capi-hip-amdgcn-amd-amdhsa-gfx950.s | head -1 | sed 's/.*num_vgpr, *//')
+  if [ -n "$nv" ] && [ "$nv" -gt 32 ]; then echo "build.sh: $k uses $nv VGPRs (> 32)" >&2; exit 1; fi
+done

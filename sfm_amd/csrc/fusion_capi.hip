@@ -399,13 +399,17 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
 {
     const size_t n = c->frames.size();
     const uint64_t list_cap = shard_cap * kListShards;
+    if (shard_cap > 0xFFF00000ull)  // table_group_kernel walks a shard with 32-bit offsets (and a grid-sized stride)
+        return fail(c, SFM_E_UNSUPPORTED, "more than 2^32 list entries per shard");
     int rc;
     if ((rc = ensure(c, c->d_table, table_cap))) return rc;
     if ((rc = ensure(c, c->d_list_key, list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_tag, list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_xyz, 3 * list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_bgr, list_cap))) return rc;
-    if ((rc = ensure(c, c->d_cand, list_cap))) return rc;
+    // + the unused chunk tails of table_group_kernel's waves: at most two chunks per wave and launch
+    if ((rc = ensure(c, c->d_cand, list_cap + (uint64_t)((c->frames.size() + kGroup - 1) / kGroup) * c->table_wgs *
+                                                  kListShards * 4 * 2 * kCandChunk))) return rc;
     if ((rc = ensure(c, c->d_out_key, out_cap))) return rc;
     if ((rc = ensure(c, c->d_out_tag, out_cap))) return rc;
     if ((rc = ensure(c, c->d_out_xyz, 3 * out_cap))) return rc;
@@ -589,8 +593,9 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             t.f0 = (uint32_t)g0;
             t.f1 = (uint32_t)g1;
             t.group = (uint32_t)g;
-            if (!std::getenv("SFM_DIAG_SKIP_TABLE")) {  // diagnostic only: timing of the chain without its co-runner (no output points)
-                hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, kListShards), dim3(256), 0, sb, t);
+            const char *diag = std::getenv("SFM_DIAG_SKIP_TABLE");  // diagnostic only: 1 = chain without its co-runner, 2 = half the shards (wrong cloud)
+            if (!diag || diag[0] == '2') {
+                hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, diag ? kListShards / 2 : kListShards), dim3(256), 0, sb, t);
                 // the group's winners are final now (later groups hold later keyframes): gather them
                 HIP_TRY(c, hipMemcpyAsync(c->d_cand_end.p + g, &dev_ctr(c)->cand_count, sizeof(unsigned long long),
                                           hipMemcpyDeviceToDevice, sb));

@@ -1260,6 +1260,12 @@ struct TableArgs {
 // dense_reconstruction.cpp:283-287 applied at :119 and :57), and count the voxels each
 // keyframe touches (= size of its per-frame filter output).  Stale plain reads are safe:
 // keys never change once set, tags only decrease, mark bits only accumulate within a group.
+// The kernel is latency-bound (a few resident waves per CU on purpose, it shares the CUs with the
+// keyframe chain), so an entry costs as few dependent round trips as possible: tag and key together,
+// the slot's key and tag in one read, the atomicMin and the mark's read in flight together, and
+// candidate-list space reserved per wave in chunks of kCandChunk (one reservation per ~25 iterations,
+// no workgroup-wide sync in the loop).  A chunk's unused tail is filled with kEmpty; finalize_kernel skips those.
+constexpr unsigned kCandChunk = 128;
 __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
 {
     __shared__ unsigned int s_before[kGroup], s_after[kGroup];
@@ -1274,29 +1280,34 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
     if (end > a.list.shard_cap) end = a.list.shard_cap;
     const unsigned long long base = (unsigned long long)shard * a.list.shard_cap;
     const unsigned long long want_hi = (unsigned long long)a.group + 1ull;
-    unsigned claims = 0, maxprobe = 0;
-    __shared__ unsigned int s_ncand;
-    __shared__ unsigned long long s_cbase;
-    if (threadIdx.x == 0) s_ncand = 0;
     const unsigned lane = lane_id();
-    // block-uniform trip count: the candidate append below synchronises the workgroup
-    for (unsigned long long i0 = begin + (unsigned long long)blockIdx.x * blockDim.x; i0 < end;
-         i0 += (unsigned long long)gridDim.x * blockDim.x) {
-        const unsigned long long i = i0 + threadIdx.x;
-        const unsigned long long tag = i < end ? a.list.tag[base + i] : kEmpty;
+    unsigned long long cbase = 0;  // wave-uniform: this wave's chunk of the candidate list
+    unsigned cleft = 0;
+    // positions as 32-bit offsets from the group's first entry of the shard (host: shard_cap < 2^32)
+    const unsigned long long *tagp = a.list.tag + base + begin, *keyp = a.list.key + base + begin;
+    const uint32_t n = end > begin ? (uint32_t)(end - begin) : 0u;
+    for (uint32_t r0 = blockIdx.x * blockDim.x; r0 < n; r0 += gridDim.x * blockDim.x) {
+        const uint32_t r = r0 + threadIdx.x;
+        const uint32_t rc = r < n ? r : n - 1;  // both loads unconditional: one round trip
+        const unsigned long long tag_ld = tagp[rc];
+        const unsigned long long key = keyp[rc];   // unwritten (but readable) where the tag is empty
+        const unsigned long long tag = r < n ? tag_ld : kEmpty;
         bool lower = false;
         if (tag != kEmpty) {
-            const unsigned long long key = a.list.key[base + i];
             const uint32_t fr = (uint32_t)(tag >> 32) - a.f0;
             atomicAdd(&s_before[fr], 1u);
             uint64_t h = mix64(key) & a.table_mask;
             unsigned probes = 0;
             bool found = false;
+            unsigned long long seen = kEmpty;  // the slot's tag as last seen
             for (;;) {
-                unsigned long long cur = a.table[h].key;
+                const ulonglong2 s01 = *reinterpret_cast<const ulonglong2 *>(a.table + h);  // key and tag in one read
+                unsigned long long cur = s01.x;
+                seen = s01.y;
                 if (cur == kEmpty) {
                     cur = atomicCAS(&a.table[h].key, kEmpty, key);
-                    if (cur == kEmpty) { claims++; cur = key; }
+                    if (cur == kEmpty) { atomicAdd(&s_claims, 1u); cur = key; }
+                    seen = kEmpty;  // claimed this instant: the atomicMin below sees whatever the tag is by now
                 }
                 if (cur == key) { found = true; break; }
                 h = (h + 1) & a.table_mask;
@@ -1305,15 +1316,15 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
             if (!found) {
                 s_err = kErrTableFull;
             } else {
-                if (probes > maxprobe) maxprobe = probes;
-                const unsigned long long seen = a.table[h].tag;
+                if (probes) atomicMax(&s_maxprobe, probes);
+                // the atomicMin and the read of the mark are in flight together
                 unsigned long long prev_tag = seen;
                 if (seen > tag) prev_tag = atomicMin(&a.table[h].tag, tag);
+                unsigned long long old = a.table[h].mark;  // a fresh slot holds kEmpty: no group has that id
                 // Only an entry that was its voxel's smallest tag at this moment can still win:
                 // it goes on the candidate list that finalize_kernel walks.
                 lower = prev_tag > tag;
                 const unsigned long long bit = 1ull << fr;
-                unsigned long long old = a.table[h].mark;  // a fresh slot holds kEmpty: no group has that id
                 for (;;) {
                     const bool same = (old >> 32) == want_hi;
                     if (same && (old & bit)) break;
@@ -1324,24 +1335,24 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
                 }
             }
         }
-        // candidate append: wave ballot -> one LDS add per wave -> one global add per workgroup
+        // candidate append into the wave's chunk
         const unsigned long long m = __ballot(lower);
-        unsigned wbase = 0;
         if (m != 0) {
-            const int leader = __ffsll((long long)m) - 1;
-            if ((int)lane == leader) wbase = atomicAdd(&s_ncand, (unsigned)__popcll(m));
-            wbase = __shfl(wbase, leader);
+            const unsigned cnt = (unsigned)__popcll(m);
+            if (cnt > cleft) {  // wave-uniform; cleft < cnt <= 64
+                if (lane < cleft) a.cand[cbase + lane] = kEmpty;
+                unsigned long long nb = 0;
+                if (lane == 0) nb = atomicAdd(&a.ctr->cand_count, (unsigned long long)kCandChunk);
+                cbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(nb >> 32)) << 32) |
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)nb);
+                cleft = kCandChunk;
+            }
+            if (lower) a.cand[cbase + (unsigned)__popcll(m & lanemask_lt())] = base + begin + r;
+            cbase += cnt;
+            cleft -= cnt;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            s_cbase = s_ncand ? atomicAdd(&a.ctr->cand_count, (unsigned long long)s_ncand) : 0ull;
-            s_ncand = 0;
-        }
-        __syncthreads();
-        if (lower) a.cand[s_cbase + wbase + (unsigned)__popcll(m & lanemask_lt())] = base + i;
     }
-    if (claims) atomicAdd(&s_claims, claims);
-    if (maxprobe) atomicMax(&s_maxprobe, maxprobe);
+    for (unsigned q = lane; q < cleft; q += 64) a.cand[cbase + q] = kEmpty;
     __syncthreads();
     if (threadIdx.x < kGroup && a.f0 + threadIdx.x < a.f1) {
         if (s_before[threadIdx.x]) atomicAdd(&a.frame_before[a.f0 + threadIdx.x], (unsigned long long)s_before[threadIdx.x]);
@@ -1377,10 +1388,11 @@ struct FinalizeArgs {
 // A candidate is an output point iff its tag is the minimum recorded for its voxel.  One launch per
 // group of keyframes, right behind the group's table kernel: later groups hold later keyframes only,
 // whose tags are larger, so a group's winners are final as soon as the group is in the table.
-// Output space for a 256-thread block's winners: kFinItems candidates per thread, one global
+// Output space for a 256-thread block's winners: kFinItems candidates per thread (independent
+// probes, but one after the other: more items only pay where the counter is the bottleneck), one global
 // atomic per block and tile (one per wave serialises on the counter's address: 25 k atomics at
 // ~90 per microsecond for a C2 cloud).  Every thread of the block must call it.
-constexpr int kFinItems = 4;
+template <int kFinItems>
 __device__ __forceinline__ void block_reserve(const bool (&win)[kFinItems], unsigned long long *counter,
                                               unsigned int *s_w, unsigned long long *s_base,
                                               unsigned long long (&off)[kFinItems])
@@ -1409,6 +1421,7 @@ __device__ __forceinline__ void block_reserve(const bool (&win)[kFinItems], unsi
 
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
 {
+    constexpr int kFinItems = 1;  // per group: a few thousand tiles, latency-bound probes
     __shared__ unsigned int s_w[4];
     __shared__ unsigned long long s_base;
     const unsigned long long begin = a.group ? a.cand_end[a.group - 1] : 0ull;
@@ -1423,8 +1436,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
             const unsigned long long i = begin + tile * tile_sz + (unsigned)j * 256u + threadIdx.x;
             win[j] = false;
             key[j] = tag[j] = e[j] = 0;
-            if (i < n) {
-                e[j] = a.cand[i];
+            if (i < n) e[j] = a.cand[i];
+            if (i < n && e[j] != kEmpty) {  // kEmpty: the unused tail of a wave's chunk
                 tag[j] = a.list.tag[e[j]];
                 key[j] = a.list.key[e[j]];
                 uint64_t h = mix64(key[j]) & a.table_mask;
@@ -1565,6 +1578,7 @@ __global__ __launch_bounds__(256) void merge_finalize_kernel(const Record *rec, 
                                                              double *out_xyz, uint32_t *out_bgr,
                                                              unsigned long long *out_key, unsigned long long *out_tag)
 {
+    constexpr int kFinItems = 4;  // the whole cloud at once: the counter would serialise 25 k wave atomics
     __shared__ unsigned int s_w[4];
     __shared__ unsigned long long s_base;
     const unsigned long long tile_sz = 256ull * kFinItems;
