@@ -593,9 +593,12 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             t.f0 = (uint32_t)g0;
             t.f1 = (uint32_t)g1;
             t.group = (uint32_t)g;
-            const char *diag = std::getenv("SFM_DIAG_SKIP_TABLE");  // diagnostic only: 1 = chain without its co-runner, 2 = half the shards (wrong cloud)
-            if (!diag || diag[0] == '2') {
-                hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, diag ? kListShards / 2 : kListShards), dim3(256), 0, sb, t);
+            // diagnostic only (wrong or no cloud): 1 = chain without its co-runner, 2 / 3 = half / an eighth of the
+            // shards, 4 = finalize_kernel only
+            const char *diag = std::getenv("SFM_DIAG_SKIP_TABLE");
+            if (!diag || diag[0] != '1') {
+                const uint32_t shards = !diag ? kListShards : diag[0] == '2' ? kListShards / 2 : diag[0] == '3' ? kListShards / 8 : 0;
+                if (shards) hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, shards), dim3(256), 0, sb, t);
                 // the group's winners are final now (later groups hold later keyframes): gather them
                 HIP_TRY(c, hipMemcpyAsync(c->d_cand_end.p + g, &dev_ctr(c)->cand_count, sizeof(unsigned long long),
                                           hipMemcpyDeviceToDevice, sb));
