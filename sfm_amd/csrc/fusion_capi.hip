@@ -131,6 +131,7 @@ struct sfm_fusion_ctx {
     // the kernel is off the keyframe chain, and a chip-filling grid slows the chain kernels it
     // overlaps by more than it gains (r01v6 sweep: 64 -> 14.7 ms, 16 -> 13.2 ms, 4 -> 13.9 ms per C2 run)
     uint32_t table_wgs = 16;
+    uint32_t table_threads = 256;    // threads per table_group_kernel workgroup (SFM_TABLE_THREADS: 64, 128 or 256)
     uint32_t waves_per_cu = 28;      // resident observe waves per CU (SFM_FUSE_RESIDENT overrides)
     bool profile = false;         // per-launch start/stop events on the frame kernels
     std::vector<hipEvent_t> kev;  // 2 per keyframe when profiling
@@ -598,7 +599,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             const char *diag = std::getenv("SFM_DIAG_SKIP_TABLE");
             if (!diag || diag[0] != '1') {
                 const uint32_t shards = !diag ? kListShards : diag[0] == '2' ? kListShards / 2 : diag[0] == '3' ? kListShards / 8 : 0;
-                if (shards) hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, shards), dim3(256), 0, sb, t);
+                if (shards) hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, shards), dim3(c->table_threads), 0, sb, t);
                 // the group's winners are final now (later groups hold later keyframes): gather them
                 HIP_TRY(c, hipMemcpyAsync(c->d_cand_end.p + g, &dev_ctr(c)->cand_count, sizeof(unsigned long long),
                                           hipMemcpyDeviceToDevice, sb));
@@ -706,6 +707,10 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
     }
     if (const char *e = std::getenv("SFM_FUSE_CHAIN")) c->chain = std::atoi(e) != 0;
     if (const char *e = std::getenv("SFM_CHAIN_COOP")) c->chain_coop = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SFM_TABLE_THREADS")) {
+        const int v = std::atoi(e);
+        if (v == 64 || v == 128 || v == 256) c->table_threads = (uint32_t)v;
+    }
     if (const char *e = std::getenv("SFM_TABLE_WGS")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 1024) c->table_wgs = (uint32_t)v;
