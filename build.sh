@@ -13,21 +13,22 @@ if [ ! -f build/cloud_sort.o ] || [ sfm_amd/csrc/cloud_sort.hip -nt build/cloud_
   hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -c sfm_amd/csrc/cloud_sort.hip -o build/cloud_sort.o
 fi
 hipcc --offload-arch=gfx950 -fPIC -shared build/fusion_capi.o build/cloud_sort.o -o build/libsfm_fusion.so
-cp build/libsfm_fusion.so sfm_amd/lib/libsfm_fusion.so
 # C++ facade example (host-only code over the C ABI); run by tests/test_gpu_cpp_facade.py
-g++ -std=c++17 -O2 -Wall -pthread sfm_amd/cpp/facade_example.cpp -Lsfm_amd/lib -lsfm_fusion \
+g++ -std=c++17 -O2 -Wall -pthread sfm_amd/cpp/facade_example.cpp -Lbuild -lsfm_fusion \
   -Wl,-rpath,'$ORIGIN/../lib' -o sfm_amd/cpp/facade_example
-g++ -std=c++17 -O2 -Wall -pthread sfm_amd/cpp/replay_reconstruct.cpp -Lsfm_amd/lib -lsfm_fusion \
+g++ -std=c++17 -O2 -Wall -pthread sfm_amd/cpp/replay_reconstruct.cpp -Lbuild -lsfm_fusion \
   -Wl,-rpath,'$ORIGIN/../lib' -o sfm_amd/cpp/replay_reconstruct
 # host-only formatter probe used by tests/test_writer_parity.py
 g++ -std=c++17 -O2 -Wall -pthread tests/cpp/writer_probe.cpp -o build/writer_probe
 g++ -std=c++17 -O2 -Wall tests/cpp/recording_probe.cpp -lz -o build/recording_probe
 # fuse_chain_kernel must leave VGPRs for a co-resident table-kernel wave (see the kernel's comment)
-nv=$(grep -E "fuse_chain_kernel.*\.num_vgpr," build/fusion_capi-hip-amdgcn-amd-amdhsa-gfx950.s | head -1 | sed 's/.*num_vgpr, *//')
-if [ -n "$nv" ] && [ "$nv" -gt 120 ]; then echo "build.sh: fuse_chain_kernel uses $nv VGPRs (> 120)" >&2; exit 1; fi
+for nv in $(grep -E "fuse_chain_kernel.*\.num_vgpr," build/fusion_capi-hip-amdgcn-amd-amdhsa-gfx950.s | sed 's/.*num_vgpr, *//'); do
+  if [ "$nv" -gt 120 ]; then echo "build.sh: fuse_chain_kernel uses $nv VGPRs (> 120)" >&2; exit 1; fi
+done
 # ... and the kernels that run beside it on stream B must fit into what it leaves: 512 - 4 * 120 = 32 VGPRs per SIMD
 # (a table kernel with 43 VGPRs waited for whole chain launches to end: 8.1 -> 11 ms per C2 run)
 for k in table_group_kernel finalize_kernel; do
   nv=$(grep -E "sfm[0-9]+${k}E.*\.num_vgpr," build/fusion_capi-hip-amdgcn-amd-amdhsa-gfx950.s | head -1 | sed 's/.*num_vgpr, *//')
   if [ -n "$nv" ] && [ "$nv" -gt 32 ]; then echo "build.sh: $k uses $nv VGPRs (> 32)" >&2; exit 1; fi
 done
+cp build/libsfm_fusion.so sfm_amd/lib/libsfm_fusion.so

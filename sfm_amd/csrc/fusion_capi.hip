@@ -530,7 +530,8 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             if (c->profile) HIP_TRY(c, hipEventRecord(c->kev[4 * g], sa));
             if (c->chain_coop) {
                 void *args[] = {(void *)&fr, (void *)&np, (void *)&ca};
-                if (hipLaunchCooperativeKernel((const void *)fuse_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), args,
+                const void *kern = c->n_cu == 256 ? (const void *)fuse_chain_kernel : (const void *)fuse_chain_kernel_any;
+                if (hipLaunchCooperativeKernel(kern, dim3(c->n_cu), dim3(kChainThreads), args,
                                                (unsigned int)c->chain_lds, sa) != hipSuccess) {
                     // the runtime refuses the grid (fewer CUs available than the device reports):
                     // same outcome as a barrier timeout -- the caller reruns with the kernel pair
@@ -541,7 +542,10 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
                     return SFM_OK;
                 }
             } else {
-                hipLaunchKernelGGL(fuse_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa, fr, np, ca);
+                if (c->n_cu == 256)  // XCD-aware piece mapping (8 XCDs x 32 CUs)
+                    hipLaunchKernelGGL(fuse_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa, fr, np, ca);
+                else
+                    hipLaunchKernelGGL(fuse_chain_kernel_any, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa, fr, np, ca);
             }
             if (c->profile) HIP_TRY(c, hipEventRecord(c->kev[4 * g + 1], sa));
         } else
@@ -698,8 +702,8 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
         if (items >= 8 && (coop || !c->chain_coop)) {
             c->chain_items = items;
             c->chain_lds = chain_lds_bytes(items);
-            if (hipFuncSetAttribute((const void *)fuse_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)c->chain_lds) != hipSuccess) {
+            const void *kern = c->n_cu == 256 ? (const void *)fuse_chain_kernel : (const void *)fuse_chain_kernel_any;
+            if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->chain_lds) != hipSuccess) {
                 (void)hipGetLastError();
                 c->chain_items = 0;
             }

@@ -796,14 +796,40 @@ __device__ __forceinline__ bool chain_wait(unsigned int *bar, unsigned epoch, un
 // The part of step A that does not depend on the visibility masks, for the workgroup's pixels of
 // one pass: validity (:100-101 without the mask), covariance gate (:136-140), back-projection
 // (:143-144).  It runs for keyframe f+1 while the workgroup waits at the barrier after keyframe f.
-// Pixels are dealt in pieces of 16: piece r of workgroup b is G*r + (b + 97 r) mod G, so that a run
-// of live pixels is shared by several workgroups and every workgroup samples the whole image.
+// Pixels are dealt in pieces of 16 (chain_piece), so that a run of live pixels is shared by several
+// workgroups and every workgroup samples the whole image.
 constexpr int kPiece = 16;
 struct ChainPre {
     uint32_t pixel[kChainSegs];
     bool cand[kChainSegs];                 // in the image, depth > 0, gate passed
     double pwx[kChainSegs], pwy[kChainSegs], pwz[kChainSegs];
 };
+
+// Piece `pr` of workgroup b (a bijection between the workgroups and the pieces [G*pr, G*(pr+1))).
+// On the full chip (G = 256 = 8 XCDs x 32 CUs; workgroup b runs on XCD b mod 8) the pieces are dealt
+// XCD-aware: a round is four groups of eight 128-pixel superpieces, XCD x takes one superpiece of
+// each group (rotated by three per group so that no XCD keeps an image column), and the XCD's 32
+// workgroups share its 32 pieces (rotated per round).  Every 128-byte line of the keyframe's depth,
+// mask and colour, and the lines its pixels project to in the neighbours' depth images, are then
+// fetched into ONE XCD's L2 instead of (nearly) all eight: FETCH_SIZE of a C2 launch fell from 197 to
+// 87 MiB.  The run time did not follow (8.12 -> 8.19 ms; 64-pixel superpieces 8.58, 256-pixel 8.26):
+// the gathers' latency is the same from the local L2 and from the Infinity Cache.
+#ifndef SFM_XCD_SP
+#define SFM_XCD_SP 8
+#endif
+template <bool XCD8>
+__device__ __forceinline__ uint32_t chain_piece(uint32_t pr, unsigned b, unsigned G)
+{
+    if (XCD8) {  // the host launches this instantiation with G == 256 only
+        constexpr uint32_t kSp = SFM_XCD_SP;            // pieces per superpiece
+        constexpr uint32_t kSpShift = kSp == 16 ? 4 : kSp == 8 ? 3 : 2;
+        const uint32_t x = b & 7u, jj = ((b >> 3) + 13u * pr) & 31u;
+        const uint32_t gl = jj >> kSpShift, q = jj & (kSp - 1u);
+        const uint32_t t = (x - 3u * ((32u / kSp) * pr + gl)) & 7u;
+        return 256u * pr + gl * (8u * kSp) + t * kSp + q;
+    }
+    return G * pr + (b + 97u * pr) % G;
+}
 
 __device__ __forceinline__ uint32_t chain_slots(const FrameDev &F, unsigned G)
 {
@@ -814,6 +840,7 @@ __device__ __forceinline__ uint32_t chain_slots(const FrameDev &F, unsigned G)
     return (piece_rounds + (kWave / kPiece) - 1) / (kWave / kPiece);  // 64-lane slots per workgroup
 }
 
+template <bool XCD8>
 __device__ __forceinline__ void chain_prepare(const FrameDev &F, const DevParams &P, uint32_t i0, unsigned w,
                                               unsigned lane, unsigned b, unsigned G, ChainPre &r)
 {
@@ -826,7 +853,7 @@ __device__ __forceinline__ void chain_prepare(const FrameDev &F, const DevParams
     for (int u = 0; u < kChainSegs; u++) {
         const uint32_t i = i0 + (uint32_t)u * kChainWaves + w;
         const uint32_t pr = i * (kWave / kPiece) + lane / kPiece;
-        const uint32_t piece = G * pr + (b + 97u * pr) % G;
+        const uint32_t piece = chain_piece<XCD8>(pr, b, G);
         r.pixel[u] = piece * kPiece + lane % kPiece;
         r.cand[u] = (i < slots) && (r.pixel[u] < npx);
         dv[u] = ldg(F.depth + (r.cand[u] ? r.pixel[u] : 0u));
@@ -962,8 +989,9 @@ __device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, co
 // waves per SIMD that leaves 32 of the 512 registers per lane for a wave of the table kernel of the
 // previous group.  At 121+ the allocation is 128, the CU is full, the chain workgroups cannot be placed
 // before that kernel has drained, and every launch loses its ~200 us.
-__global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDev *__restrict__ frames,
-                                                                   const FrameDev *__restrict__ nbrpack, ChainArgs a)
+template <bool XCD8>
+__device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ frames,
+                                                const FrameDev *__restrict__ nbrpack, const ChainArgs &a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const unsigned lane = lane_id();
@@ -987,7 +1015,7 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
 
     ChainPre pre;
     unsigned pf_v = 0;
-    chain_prepare(frames[a.f0], P, 0, w, lane, b, G, pre);
+    chain_prepare<XCD8>(frames[a.f0], P, 0, w, lane, b, G, pre);
     for (uint32_t f = a.f0; f < a.f1; f++) {
         SFM_CSTAMP(0);
         if (f > a.f0) {
@@ -1027,7 +1055,7 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
             if (threadIdx.x == 0) s_misc[0] = 0;
             __syncthreads();
             // ---- A: the mask-independent part was prepared ahead for the first pass
-            if (i0 || part) chain_prepare(F, P, i0, w, lane, b, G, pre);
+            if (i0 || part) chain_prepare<XCD8>(F, P, i0, w, lane, b, G, pre);
             uint32_t pos[kChainSegs], mv[kChainSegs];
 #if SFM_REPEAT == 4
             {  // diagnostic: the mask read and a ballot once more, discarded
@@ -1226,7 +1254,7 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
                     pf_v = ldg(reinterpret_cast<const unsigned *>(pf + threadIdx.x * 64u));
             }
             // ... and do its mask-independent work
-            chain_prepare(frames[f + 1], P, 0, w, lane, b, G, pre);
+            chain_prepare<XCD8>(frames[f + 1], P, 0, w, lane, b, G, pre);
         }
     }
     const unsigned any_err = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(err != 0) != 0ull));
@@ -1239,6 +1267,20 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDe
         if (c_hit) atomicAdd(&st->n_hit, (unsigned long long)c_hit);
         if (err) atomicOr(&st->err, err);
     }
+}
+
+// The two instantiations: fuse_chain_kernel for the full chip (256 workgroups, XCD-aware pieces),
+// fuse_chain_kernel_any for any other grid.
+__global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDev *__restrict__ frames,
+                                                                   const FrameDev *__restrict__ nbrpack, ChainArgs a)
+{
+    fuse_chain_body<true>(frames, nbrpack, a);
+}
+
+__global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel_any(const FrameDev *__restrict__ frames,
+                                                                       const FrameDev *__restrict__ nbrpack, ChainArgs a)
+{
+    fuse_chain_body<false>(frames, nbrpack, a);
 }
 
 // ---- voxel table: first-wins filter for a group of keyframes ------------------------------
