@@ -21,6 +21,8 @@ g++ -std=c++17 -O2 -Wall -pthread sfm_amd/cpp/replay_reconstruct.cpp -Lbuild -ls
 # host-only formatter probe used by tests/test_writer_parity.py
 g++ -std=c++17 -O2 -Wall -pthread tests/cpp/writer_probe.cpp -o build/writer_probe
 g++ -std=c++17 -O2 -Wall tests/cpp/recording_probe.cpp -lz -o build/recording_probe
+# GPU unit test of the shared-reciprocal division pair; run by tests/test_gpu_div_pair.py
+hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 tests/hip/div_probe.hip -o build/div_probe
 # fuse_chain_kernel must leave VGPRs for a co-resident table-kernel wave (see the kernel's comment)
 for nv in $(grep -E "fuse_chain_kernel.*\.num_vgpr," build/fusion_capi-hip-amdgcn-amd-amdhsa-gfx950.s | sed 's/.*num_vgpr, *//'); do
   if [ "$nv" -gt 120 ]; then echo "build.sh: fuse_chain_kernel uses $nv VGPRs (> 120)" >&2; exit 1; fi

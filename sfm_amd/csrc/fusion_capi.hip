@@ -497,6 +497,10 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     bool use_chain = c->chain && c->chain_items > 0;
     for (size_t i = 0; use_chain && i < n; i++)
         if (c->frames[i].n_filtered > c->chain_items) use_chain = false;
+    // ... and its unchecked shared-reciprocal divisions need operands in their range (chain_div_ok)
+    for (size_t i = 0; use_chain && i < n; i++)
+        if (!chain_div_ok(a.P, c->frames[i].K, c->frames[i].W, c->frames[i].H, c->h_frames[i].Twk, c->h_frames[i].Tkw))
+            use_chain = false;
     c->chain_ran = use_chain;
     for (size_t g = 0; g < n_groups; g++) {
         const size_t g0 = g * kGroup, g1 = std::min(n, g0 + kGroup);
@@ -921,10 +925,12 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
         if ((rc = run_once(c, table_cap, shard_cap, out_cap, &err))) return rc;
         const bool crowded = !err && !fixed_tab && c->h_small->ctr.table_used * 2 > table_cap;
         if (!err && !crowded) break;
-        if (err & kErrBarrier) {
-            // The persistent kernel's workgroups were not all resident within the time limit (another
-            // process or stream holds CUs).  Nothing hangs: every workgroup has left.  This ctx goes
-            // on with the per-keyframe kernel pair, which needs no co-residency.
+        if (err & (kErrBarrier | kErrDivRange)) {
+            // kErrBarrier: the persistent kernel's workgroups were not all resident within the time limit
+            // (another process or stream holds CUs).  Nothing hangs: every workgroup has left.
+            // kErrDivRange: a division operand outside the range of the chain kernel's shared-reciprocal
+            // divisions (|x| < 2^-400 or > 2^400).  Either way this ctx goes on with the per-keyframe
+            // kernel pair, which needs no co-residency and divides plainly.
             if (!c->chain) return fail(c, SFM_E_HIP, "device-wide barrier timed out");
             c->chain = false;
             c->chain_fallbacks++;

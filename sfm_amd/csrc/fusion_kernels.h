@@ -59,6 +59,7 @@ constexpr uint32_t kErrKeyRange = 2u;
 constexpr uint32_t kErrListFull = 4u;
 constexpr uint32_t kErrBarrier = 8u;  // fuse_chain_kernel: a device-wide barrier timed out
 constexpr uint32_t kErrOutFull = 16u;  // finalize_kernel: more winners than output slots
+constexpr uint32_t kErrDivRange = 32u; // fuse_chain_kernel: a division operand outside div_pair's range
 
 struct FrameDev {
     double K[4];      // fx fy cx cy
@@ -138,14 +139,52 @@ __device__ __forceinline__ double cov_trace(const DevParams &P, int u, int v, do
     return P00 + (P11 + P22);
 }
 
+// n0/d and n1/d, bit for bit what two IEEE divisions give.  Shared modes: the reciprocal and its
+// refinement are computed once.  It is the compiler's own f64 division sequence (v_div_scale, v_rcp, two Newton
+// steps, quotient, residual, v_div_fmas, v_div_fixup) for operands that v_div_scale leaves alone: |d|
+// and every |n| either zero, infinite, NaN (v_div_fixup decides those from the operands, whatever the
+// arithmetic produced) or within [2^-400, 2^400].  A finite non-zero operand outside that range sets
+// `bad` in the checked mode (tests/hip/div_probe.hip); the kernels use the unchecked mode and the host
+// (chain_div_ok) sends inputs that could leave the range to the kernel pair, which divides plainly.  A pair costs 17 instructions instead of 22 and one v_rcp_f64 (16 cycles) instead of two.
+// true: x is finite, not zero, and outside [2^-400, 2^400] (from the exponent field alone)
+__device__ __forceinline__ bool div_operand_bad(double x)
+{
+    const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0x7FFu;
+    if (e == 0u) return x != 0.0;                 // denormal
+    return e != 0x7FFu && (e - 623u) > 800u;     // 623 = 1023 - 400
+}
+
+enum DivMode { kDivPlain, kDivShared, kDivSharedChecked };
+template <DivMode MODE>
+__device__ __forceinline__ void div_pair(double n0, double n1, double d, double &q0, double &q1, bool &bad)
+{
+    if (MODE == kDivPlain) {
+        q0 = n0 / d;
+        q1 = n1 / d;
+        return;
+    }
+    // kDivShared: the caller's operands were validated elsewhere (host, sfm_fusion_run)
+    if (MODE == kDivSharedChecked) bad = bad || div_operand_bad(d) || div_operand_bad(n0) || div_operand_bad(n1);
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double t0 = n0 * r, t1 = n1 * r;
+    q0 = __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-d, t0, n0), r, t0), d, n0);
+    q1 = __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-d, t1, n1), r, t1), d, n1);
+}
+
 // Same value as cov_trace(), bit for bit, with the four divisions that depend on the depth
 // alone taken from the per-focal-length table e = ctab + 4*depth:
 //   e[0] = (J00*S0)*J00, e[1] = (J00*S1)*J00, e[2] = disparity^2, e[3] = (J22*S2)*J22.
-__device__ __forceinline__ double cov_trace_vals(const DevParams &P, int u, int v, double2 e01, double2 e23)
+template <bool SHARED>
+__device__ __forceinline__ double cov_trace_vals(const DevParams &P, int u, int v, double2 e01, double2 e23, bool &bad)
 {
     const double dd = e23.x;
-    const double J02 = ((double)(-u) * P.base_line) / dd;
-    const double J12 = ((double)(-v) * P.base_line) / dd;
+    double J02, J12;
+    // shared: sfm_fusion_run has checked the table's range of disparity^2 and of the numerators (chain_div_ok)
+    div_pair<SHARED ? kDivShared : kDivPlain>((double)(-u) * P.base_line, (double)(-v) * P.base_line, dd, J02, J12, bad);
     const double P00 = e01.x + (J02 * P.S2) * J02;
     const double P11 = e01.y + (J12 * P.S2) * J12;
     return P00 + (P11 + e23.y);
@@ -153,7 +192,8 @@ __device__ __forceinline__ double cov_trace_vals(const DevParams &P, int u, int 
 
 __device__ __forceinline__ double cov_trace_tab(const DevParams &P, int u, int v, const double *e)
 {
-    return cov_trace_vals(P, u, v, *reinterpret_cast<const double2 *>(e), *reinterpret_cast<const double2 *>(e + 2));
+    bool bad = false;
+    return cov_trace_vals<false>(P, u, v, *reinterpret_cast<const double2 *>(e), *reinterpret_cast<const double2 *>(e + 2), bad);
 }
 
 // One entry per raw depth value for focal length f; the operations and their order are those
@@ -440,13 +480,18 @@ struct ObsProj {
 };
 
 // KeyFrame::point_in_frame, keyframe.cpp:275-294 / pinhole.cpp:32-45
-__device__ __forceinline__ ObsProj obs_project(const FrameDev &L, double pwx, double pwy, double pwz, bool on)
+template <bool SHARED>
+__device__ __forceinline__ ObsProj obs_project(const FrameDev &L, double pwx, double pwy, double pwz, bool on, bool &bad)
 {
     const double cx_ = row_apply(L.Tkw, 0, pwx, pwy, pwz);
     const double cy_ = row_apply(L.Tkw, 1, pwx, pwy, pwz);
     const double cz_ = row_apply(L.Tkw, 2, pwx, pwy, pwz);
-    const double px = (cx_ / cz_) * L.K[0] + L.K[2];
-    const double py = (cy_ / cz_) * L.K[1] + L.K[3];
+    double xz, yz;
+    // shared: sfm_fusion_run has bounded the poses and intrinsics so that cx_, cy_, cz_ are zero or within
+    // div_pair's range (chain_div_ok); a check here costs more than the shared reciprocal saves
+    div_pair<SHARED ? kDivShared : kDivPlain>(cx_, cy_, cz_, xz, yz, bad);
+    const double px = xz * L.K[0] + L.K[2];
+    const double py = yz * L.K[1] + L.K[3];
     ObsProj r;
     // NaN projections are "not visible" (UB in the reference): hence the >= 0 form
     r.vis = on && (px >= 0) && (px < (double)L.W) && (py >= 0) && (py < (double)L.H) && !(cz_ < 0);
@@ -459,16 +504,17 @@ __device__ __forceinline__ ObsProj obs_project(const FrameDev &L, double pwx, do
 // dense_reconstruction.cpp:193-216 after the gathers: back-projection of the neighbour's depth,
 // its covariance trace (bit-equal to cov_trace_tab), the kept (:204) / close (:224) tests, and the
 // weighted observation (:161-162) left in LDS for the fusing wave.
+template <bool SHARED>
 __device__ __forceinline__ void obs_finish(const FrameDev &L, const DevParams &P, const ObsProj &p, uint32_t draw,
                                            double x, double y, double2 e01, double2 e23, double pwx, double pwy,
-                                           double pwz, double *o, uint32_t *hit, bool &kept, bool &close)
+                                           double pwz, double *o, uint32_t *hit, bool &kept, bool &close, bool &bad)
 {
     const double d = (double)draw;
     const double qcx = x * d, qcy = y * d, qcz = d;
     const double qx = row_apply(L.Twk, 0, qcx, qcy, qcz);
     const double qy = row_apply(L.Twk, 1, qcx, qcy, qcz);
     const double qz = row_apply(L.Twk, 2, qcx, qcy, qcz);
-    const double wgt = cov_trace_vals(P, p.ix, p.iy, e01, e23);          // :202
+    const double wgt = cov_trace_vals<SHARED>(P, p.ix, p.iy, e01, e23, bad);  // :202
     kept = p.vis && (wgt < P.T_cov);                                     // :204
     const double dx = qx - pwx, dy = qy - pwy, dz = qz - pwz;
     const double s = (dx * dx + dy * dy) + dz * dz;                      // norm(): (e0+e1)+e2
@@ -550,8 +596,9 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
             const bool has1 = k1 < K;  // wave-uniform
             const FrameDev &L0 = nbp[k0];
             const FrameDev &L1 = nbp[has1 ? k1 : k0];
-            ObsProj p0 = obs_project(L0, pwx, pwy, pwz, act);
-            ObsProj p1 = obs_project(L1, pwx, pwy, pwz, act && has1);
+            bool nobad = false;  // plain divisions on this path
+            ObsProj p0 = obs_project<false>(L0, pwx, pwy, pwz, act, nobad);
+            ObsProj p1 = obs_project<false>(L1, pwx, pwy, pwz, act && has1, nobad);
             const uint32_t draw0 = ldg(L0.depth + p0.npix);              // :193 (no d>0 test)
             const uint32_t draw1 = ldg(L1.depth + p1.npix);
             const double x0 = ldg(L0.xtab + p0.ix), y0 = ldg(L0.ytab + p0.iy);
@@ -561,11 +608,11 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
             const double2 e0a = ldg2(e0), e0b = ldg2(e0 + 2);
             const double2 e1a = ldg2(e1), e1b = ldg2(e1 + 2);
             bool kept0, close0, kept1, close1;
-            obs_finish(L0, P, p0, draw0, x0, y0, e0a, e0b, pwx, pwy, pwz, s_obs + (size_t)k0 * 256 + lane,
-                       s_hit + k0 * 64 + lane, kept0, close0);
-            obs_finish(L1, P, p1, draw1, x1, y1, e1a, e1b, pwx, pwy, pwz,
+            obs_finish<false>(L0, P, p0, draw0, x0, y0, e0a, e0b, pwx, pwy, pwz, s_obs + (size_t)k0 * 256 + lane,
+                       s_hit + k0 * 64 + lane, kept0, close0, nobad);
+            obs_finish<false>(L1, P, p1, draw1, x1, y1, e1a, e1b, pwx, pwy, pwz,
                        s_obs + (size_t)(has1 ? k1 : k0) * 256 + lane, s_hit + (has1 ? k1 : k0) * 64 + lane,
-                       kept1, close1);
+                       kept1, close1, nobad);
             const unsigned long long mk0 = __ballot(kept0), mc0 = __ballot(close0);
             const unsigned long long mk1 = __ballot(kept1), mc1 = __ballot(close1);
             c_gather += (unsigned)__popcll(__ballot(p0.vis)) + (unsigned)__popcll(__ballot(p1.vis));
@@ -727,6 +774,32 @@ struct ChainArgs {
 #define SFM_CSTAMP(i) do {} while (0)
 #endif
 
+// Host: may fuse_chain_kernel's unchecked shared-reciprocal divisions be used for this keyframe?
+// (1) cov_trace_vals: operands (-u*b), (-v*b) for 1 <= u < W, 1 <= v < H (zero passes) and disparity^2
+//     of every non-zero depth, which is monotonic in the depth.
+// (2) obs_project, with this keyframe as source or as neighbour: cx_, cy_, cz_ are sums of products of
+//     pose entries, (u - cx)/fx, (v - cy)/fy and a depth in [1, 65535].  A floating-point sum that is
+//     not zero is at least an ulp of its smallest term, so with every non-zero pose entry in
+//     [2^-100, 2^100], fx, fy in [2^-40, 2^40] and |cx|, |cy| zero or in [2^-40, 2^40] the camera
+//     coordinates are zero or within [2^-398, 2^284]: inside div_pair's range.
+// Anything else (denormal-scale poses, astronomically scaled intrinsics) runs on the kernel pair.
+inline bool chain_div_ok(const DevParams &P, const double K[4], int W, int H, const double *Twk, const double *Tkw)
+{
+    auto mag = [](double x) { return x < 0 ? -x : x; };
+    auto in_range = [&](double x, double lo, double hi) { return mag(x) >= lo && mag(x) <= hi; };  // false for NaN
+    auto zero_or = [&](double x, double lo, double hi) { return x == 0.0 || in_range(x, lo, hi); };
+    const double f = K[0];
+    const double d1 = (f * P.base_line) / (1.0 / P.depth_div), d2 = (f * P.base_line) / (65535.0 / P.depth_div);
+    bool ok = in_range(d1 * d1, 0x1p-390, 0x1p390) && in_range(d2 * d2, 0x1p-390, 0x1p390) &&
+              in_range(P.base_line, 0x1p-390, 0x1p390) &&
+              in_range(P.base_line * (double)(W > H ? (W > 1 ? W : 1) : (H > 1 ? H : 1)), 0x1p-390, 0x1p390);
+    ok = ok && in_range(K[0], 0x1p-40, 0x1p40) && in_range(K[1], 0x1p-40, 0x1p40) &&
+         zero_or(K[2], 0x1p-40, 0x1p40) && zero_or(K[3], 0x1p-40, 0x1p40) && W < (1 << 24) && H < (1 << 24);
+    for (int i = 0; ok && i < 12; i++)  // rows 0..2 of both matrices (row-major device copies)
+        ok = zero_or(Twk[i], 0x1p-100, 0x1p100) && zero_or(Tkw[i], 0x1p-100, 0x1p100);
+    return ok;
+}
+
 __host__ __device__ inline size_t chain_lds_bytes(uint32_t item_cap)
 {
     return (size_t)kChainSurv * (3 * 8 + 4) + (size_t)item_cap * (4 * 64 * 8 + 64 * 4 + 16) + kMaxK * 8 +
@@ -842,8 +915,9 @@ __device__ __forceinline__ uint32_t chain_slots(const FrameDev &F, unsigned G)
 
 template <bool XCD8>
 __device__ __forceinline__ void chain_prepare(const FrameDev &F, const DevParams &P, uint32_t i0, unsigned w,
-                                              unsigned lane, unsigned b, unsigned G, ChainPre &r)
+                                              unsigned lane, unsigned b, unsigned G, ChainPre &r, unsigned &err)
 {
+    bool bad = false;
     const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
     const uint32_t slots = chain_slots(F, G);
     // slots == 0 (no pixels or no neighbours): every lane reads element 0, which the host keeps
@@ -874,7 +948,9 @@ __device__ __forceinline__ void chain_prepare(const FrameDev &F, const DevParams
     }
 #pragma unroll
     for (int u = 0; u < kChainSegs; u++) {
-        const double tr = cov_trace_vals(P, uu[u], vv[u], e01[u], e23[u]);    // :136
+        bool bd = false;
+        const double tr = cov_trace_vals<true>(P, uu[u], vv[u], e01[u], e23[u], bd);  // :136
+        bad = bad || (bd && r.cand[u]);  // lanes without a pixel compute on table entry 1
         r.cand[u] = r.cand[u] && !(tr > P.T_cov);                             // :138
         const double dsrc = (double)dv[u];
         const double pcx = xn[u] * dsrc, pcy = yn[u] * dsrc, pcz = dsrc;      // pinhole.cpp:15-19
@@ -882,6 +958,7 @@ __device__ __forceinline__ void chain_prepare(const FrameDev &F, const DevParams
         r.pwy[u] = row_apply(F.Twk, 1, pcx, pcy, pcz);
         r.pwz[u] = row_apply(F.Twk, 2, pcx, pcy, pcz);
     }
+    if (bad) err |= kErrDivRange;
 }
 
 // Step B of fuse_chain_kernel: the (chunk, neighbour) items of one round.  Item (c, k) uses LDS slot
@@ -899,9 +976,10 @@ template <bool UNI>
 __device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, const DevParams &P, uint32_t K, uint32_t rc,
                                             uint32_t c0, uint32_t n, unsigned w, unsigned lane, const double *s_pw,
                                             double *s_obs, uint32_t *s_hit, unsigned long long *s_kept,
-                                            unsigned int *cnt_now, unsigned &c_gather, bool count)
+                                            unsigned int *cnt_now, unsigned &c_gather, bool count, unsigned &err)
 {
     constexpr uint32_t kMaxIt = kChainMaxItems / kChainWaves;
+    bool bad = false;
     const uint32_t items = rc * K;
     const uint32_t g = UNI ? (uint32_t)kChainWaves / K : 0u;
     const uint32_t k_w = UNI ? w % K : 0u, c_w = UNI ? w / K : 0u;
@@ -943,7 +1021,9 @@ __device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, co
         p0.npix = 0; p0.ix = p0.iy = 0; p0.vis = false;
         if (v0) {
             const uint32_t si = min((c0 + cc0) * kWave + lane, (uint32_t)kChainSurv - 1);
-            p0 = obs_project(L, s_pw[si], s_pw[kChainSurv + si], s_pw[2 * kChainSurv + si], (c0 + cc0) * kWave + lane < n);
+            bool bd = false;
+            p0 = obs_project<true>(L, s_pw[si], s_pw[kChainSurv + si], s_pw[2 * kChainSurv + si], (c0 + cc0) * kWave + lane < n, bd);
+            bad = bad || (bd && (c0 + cc0) * kWave + lane < n);
         }
         uint32_t draw0 = 0;
         double x0 = 0, y0 = 0;
@@ -970,8 +1050,10 @@ __device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, co
 #if SFM_REPEAT == 1 && !(SFM_REPEAT_ABL & 8)
             if (!count) pq.vis = false;  // the discarded pass computes, but keeps nothing and writes nothing
 #endif
-            obs_finish(nbp[k2], P, pq, draw2, x2, y2, e2a, e2b, s_pw[si], s_pw[kChainSurv + si], s_pw[2 * kChainSurv + si],
-                       s_obs + (size_t)it * 256 + lane, s_hit + it * 64 + lane, kept, close);
+            bool bd = false;
+            obs_finish<true>(nbp[k2], P, pq, draw2, x2, y2, e2a, e2b, s_pw[si], s_pw[kChainSurv + si], s_pw[2 * kChainSurv + si],
+                       s_obs + (size_t)it * 256 + lane, s_hit + it * 64 + lane, kept, close, bd);
+            bad = bad || (bd && p2.vis);  // an invisible lane's gathers read element 0
             const unsigned long long mk = __ballot(kept);
             if (count) c_gather += (unsigned)__popcll(__ballot(p2.vis));
             if (kept && count) atomicAdd(&cnt_now[c2 * kWave + lane], close ? 0x10001u : 1u);
@@ -981,6 +1063,7 @@ __device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, co
         p2 = p1; c2 = c1; k2 = k1; v2 = v1; draw2 = draw1; x2 = x1; y2 = y1; e2a = e1a; e2b = e1b;
         p1 = p0; c1 = cc0; k1 = k0; v1 = v0; draw1 = draw0; x1 = x0; y1 = y0;
     }
+    if (bad) err |= kErrDivRange;
 }
 
 // frames = every keyframe in processing order, nbrpack = FrameDev copies of the filtered neighbours
@@ -1015,7 +1098,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
 
     ChainPre pre;
     unsigned pf_v = 0;
-    chain_prepare<XCD8>(frames[a.f0], P, 0, w, lane, b, G, pre);
+    chain_prepare<XCD8>(frames[a.f0], P, 0, w, lane, b, G, pre, err);
     for (uint32_t f = a.f0; f < a.f1; f++) {
         SFM_CSTAMP(0);
         if (f > a.f0) {
@@ -1055,7 +1138,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
             if (threadIdx.x == 0) s_misc[0] = 0;
             __syncthreads();
             // ---- A: the mask-independent part was prepared ahead for the first pass
-            if (i0 || part) chain_prepare<XCD8>(F, P, i0, w, lane, b, G, pre);
+            if (i0 || part) chain_prepare<XCD8>(F, P, i0, w, lane, b, G, pre, err);
             uint32_t pos[kChainSegs], mv[kChainSegs];
 #if SFM_REPEAT == 4
             {  // diagnostic: the mask read and a ballot once more, discarded
@@ -1120,9 +1203,9 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                     // ---- B: the (chunk, neighbour) items of this round (:187-216)
                     for (int rep = 0; rep < (SFM_REPEAT == 1 ? 2 : 1); rep++) {
                         if (kChainWaves % K == 0)
-                            chain_items<true>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, rep == 0);
+                            chain_items<true>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, rep == 0, err);
                         else
-                            chain_items<false>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, rep == 0);
+                            chain_items<false>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, rep == 0, err);
                     }
                     if (threadIdx.x == 0 && c0 == 0) *reinterpret_cast<unsigned long long *>(s_misc + 2) = res_base;
                     __syncthreads();
@@ -1254,7 +1337,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                     pf_v = ldg(reinterpret_cast<const unsigned *>(pf + threadIdx.x * 64u));
             }
             // ... and do its mask-independent work
-            chain_prepare<XCD8>(frames[f + 1], P, 0, w, lane, b, G, pre);
+            chain_prepare<XCD8>(frames[f + 1], P, 0, w, lane, b, G, pre, err);
         }
     }
     const unsigned any_err = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(err != 0) != 0ull));

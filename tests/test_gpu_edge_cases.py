@@ -164,3 +164,37 @@ def test_argument_errors():
     with pytest.raises(fusion.FusionError) as e:
         run_gpu(far, fusion.default_params())
     assert e.value.code == fusion.SFM_E_UNSUPPORTED   # > SFM_MAX_NEIGHBORS filtered neighbours
+
+
+def _run_raw(frames, gp):
+    ctx = fusion.FusionContext(gp)
+    for f in frames:
+        ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+    for i, f in enumerate(frames):
+        ctx.set_neighbors(i, f["nbrs"])
+    ctx.run()
+    xyz, bgr, key, tag = ctx.read_points()
+    st = ctx.stats()
+    fb, fa = ctx.frame_counts()
+    ctx.close()
+    return dict(xyz=xyz, bgr=bgr, key=key, tag=tag, stats=st, frame_before=fb, frame_after=fa)
+
+
+def test_division_operands_outside_the_shared_range_fall_back_to_plain_division():
+    """fuse_chain_kernel divides in pairs with a shared reciprocal, exact for operands within
+    [2^-400, 2^400]; anything else must end on the kernel pair (plain divisions), never in a wrong bit."""
+    frames = scenes.plane_pair()
+    for f in frames:
+        f["T_kw"] = f["T_kw"] * 2.0 ** -500          # camera coordinates of ~2^-495: same projections, exactly
+    op, gp = both_params()
+    want = oracle.fuse(frames, op)
+    assert want.key.shape[0] > 100
+    g = _run_raw(frames, gp)
+    assert g["stats"]["fused_chain"] == 0            # flagged in the kernel (kErrDivRange), rerun on the pair
+    assert_same_cloud(g, want)
+    frames = scenes.plane_pair()
+    op, gp = both_params(base_line=2.0 ** -450)      # disparity^2 ~ 2^-890: refused on the host before the launch
+    want = oracle.fuse(frames, op)
+    g = _run_raw(frames, gp)
+    assert g["stats"]["fused_chain"] == 0
+    assert_same_cloud(g, want)
