@@ -40,9 +40,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 def observe_bytes(st):
     """Algorithmic bytes of observe_frame_kernel (SURVEY.md 8d terms that it moves; with
-    scan_bytes() the terms of fuse_chain_kernel, which does both jobs): 2 B per neighbour depth gather, 3 B colour and one 16-B slot read+write (its
-    record hand-off to the voxel table) per accepted pixel, 1 B per mask store."""
-    return 2 * st["n_gather"] + 3 * st["n_acc"] + st["n_hit"] + 32 * st["n_acc"]
+    scan_bytes() the terms of fuse_chain_kernel, which does both jobs): 2 B per neighbour depth
+    gather, one 16-B slot read+write (its record hand-off to the voxel table) per accepted pixel,
+    1 B per mask store.  SURVEY's 3 B of colour per accepted pixel are not in it: the colour is read
+    by finalize_kernel, for the voxels' winners only (total_bytes counts 3 B per output point)."""
+    return 2 * st["n_gather"] + st["n_hit"] + 32 * st["n_acc"]
 
 
 def scan_bytes(st):
@@ -51,7 +53,7 @@ def scan_bytes(st):
 
 
 def total_bytes(st):
-    return scan_bytes(st) + observe_bytes(st) + 27 * st["n_vox"]
+    return scan_bytes(st) + observe_bytes(st) + (27 + 3) * st["n_vox"]
 
 
 def main():

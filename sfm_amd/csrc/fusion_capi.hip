@@ -112,7 +112,7 @@ struct sfm_fusion_ctx {
     DevBuf<Slot> d_table;
     DevBuf<unsigned long long> d_list_key, d_list_tag, d_out_key, d_out_tag, d_cand;
     DevBuf<double> d_list_xyz, d_out_xyz;
-    DevBuf<uint32_t> d_list_bgr, d_out_bgr;
+    DevBuf<uint32_t> d_out_bgr;
     DevBuf<unsigned long long> d_fbefore, d_fafter, d_group_end, d_cand_end;
     uint64_t out_cap = 0;              // output slots of the last run (grown on kErrOutFull)
     DevBuf<uint32_t> d_qpix;           // survivor queue of the keyframe in flight
@@ -407,7 +407,6 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     if ((rc = ensure(c, c->d_list_key, list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_tag, list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_xyz, 3 * list_cap))) return rc;
-    if ((rc = ensure(c, c->d_list_bgr, list_cap))) return rc;
     // + the unused chunk tails of table_group_kernel's waves: at most two chunks per wave and launch
     if ((rc = ensure(c, c->d_cand, list_cap + (uint64_t)((c->frames.size() + kGroup - 1) / kGroup) * c->table_wgs *
                                                   kListShards * 4 * 2 * kCandChunk))) return rc;
@@ -444,7 +443,6 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     list.key = c->d_list_key.p;
     list.tag = c->d_list_tag.p;
     list.xyz = c->d_list_xyz.p;
-    list.bgr = c->d_list_bgr.p;
     list.shard_cap = shard_cap;
     list.cursor = dev_cursor(c);
     list.group_end = c->d_group_end.p;
@@ -483,6 +481,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     fa.list = list;
     fa.cand = c->d_cand.p;
     fa.cand_end = c->d_cand_end.p;
+    fa.frames = c->d_frames.p;
     fa.group = 0;
     fa.pad = 0;
     fa.out_cap = out_cap;
@@ -764,7 +763,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     release(c->d_rd_xyz); release(c->d_rd_bgr);
     release(c->d_part); release(c->d_gorder); release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
     release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
-    release(c->d_out_tag); release(c->d_cand); release(c->d_list_xyz); release(c->d_out_xyz); release(c->d_list_bgr);
+    release(c->d_out_tag); release(c->d_cand); release(c->d_list_xyz); release(c->d_out_xyz);
     release(c->d_qpix); release(c->d_qpw); release(c->d_qcount); release(c->d_frames); release(c->d_bar);
     release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_group_end); release(c->d_cand_end);
     if (c->d_small) (void)hipFree(c->d_small);

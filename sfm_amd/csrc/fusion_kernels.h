@@ -112,7 +112,6 @@ struct ListDev {
     unsigned long long *key;
     unsigned long long *tag;
     double *xyz;             // 3 per entry
-    uint32_t *bgr;           // b | g<<8 | r<<16
     uint64_t shard_cap;
     unsigned long long *cursor;     // [kListShards * 8]  (stride 8 => one line per cursor)
     // [n_groups][kListShards * 8]: copy of cursor[] taken on the keyframe stream after the last
@@ -297,6 +296,13 @@ __device__ __forceinline__ double2 ldg2(const double *p)
 {
     const dbl2_t v = *(const __attribute__((address_space(1))) dbl2_t *)p;
     return make_double2(v.x, v.y);
+}
+// 4 bytes at any byte address in one load (HSA devices access global memory unaligned; the colour
+// buffers end with 8 bytes of slack)
+typedef uint32_t u32_unaligned_t __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t ldg_u32_unaligned(const uint8_t *p)
+{
+    return *(const __attribute__((address_space(1))) u32_unaligned_t *)p;
 }
 // visibility-mask accesses of fuse_chain_kernel: agent-scope relaxed atomics (write-through store,
 // cache-bypassing load), see the kernel's header comment
@@ -575,16 +581,12 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
         const uint32_t n_in = min(cnt_s - j * kWave, (uint32_t)kWave);
         const bool act = lane < n_in;
         const unsigned p3 = c % NW;  // the wave that finishes this chunk (spreads over the SIMDs)
-        uint32_t pix = 0, col = 0;
+        uint32_t pix = 0;
         unsigned long long base_r = 0;
         if (w == p3) {
             // list space for the chunk: issued now, consumed after the neighbour work
             if (lane == 0) base_r = atomicAdd(&a.list.cursor[(c % kListShards) * 8], (unsigned long long)n_in);
-            if (act) {                                                   // :170, features.cpp:76-80
-                pix = pix_q;
-                const uint8_t *cp = F.bgr + 3ull * pix;
-                col = (uint32_t)cp[0] | ((uint32_t)cp[1] << 8) | ((uint32_t)cp[2] << 16);
-            }
+            if (act) pix = pix_q;
         }
         SFM_STAMP_WAIT();
         SFM_STAMP(2);
@@ -696,7 +698,6 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
                         a.list.xyz[3 * idx + 0] = fx;
                         a.list.xyz[3 * idx + 1] = fy;
                         a.list.xyz[3 * idx + 2] = fz;
-                        a.list.bgr[idx] = col;
                     }
                 } else {
                     atomicOr(&a.stat[blockIdx.x % kStatShards].err, kErrListFull);
@@ -1241,11 +1242,8 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                     // ... and one wave per chunk forms the fused point and its record
                     for (int rep = 0; rep < (SFM_REPEAT == 2 ? 2 : 1); rep++)
                     if (fin) {
-                        // the colour (:170, features.cpp:76-80) is requested first and used last: its
-                        // round trip runs under the sums and the divisions
+                        // (the colour, :170, is read by finalize_kernel for the voxels' winners only)
                         const uint32_t pixf = s_spix[min(cf * kWave + lane, (uint32_t)kChainSurv - 1)];
-                        const uint8_t *cp = F.bgr + 3ull * (actf ? pixf : 0u);
-                        const uint32_t cb = ldg(cp), cg = ldg(cp + 1), cr = ldg(cp + 2);
                         const uint32_t it0 = w * K;
                         const unsigned pc = cnt_now[w * kWave + lane];
                         const unsigned n_obs = pc & 0xFFFFu, n_close = pc >> 16;
@@ -1300,7 +1298,6 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                                     a.list.xyz[3 * idx + 0] = fx;
                                     a.list.xyz[3 * idx + 1] = fy;
                                     a.list.xyz[3 * idx + 2] = fz;
-                                    a.list.bgr[idx] = cb | (cg << 8) | (cr << 16);
                                 }
                             } else {
                                 err |= kErrListFull;
@@ -1500,6 +1497,7 @@ struct FinalizeArgs {
     // cand_end[g] = number of candidates after group g's table kernel (device copy of the counter,
     // taken in stream order): this launch walks [cand_end[group-1], cand_end[group])
     const unsigned long long *cand_end;
+    const FrameDev *frames;  // every keyframe of the ctx (device copy): the winners' colours are read here
     uint32_t group, pad;
     uint64_t out_cap;  // output slots; the counter keeps counting beyond (the host grows and reruns)
     Counters *ctr;
@@ -1585,7 +1583,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
                 a.out_xyz[3 * o + 0] = a.list.xyz[3 * e[j] + 0];
                 a.out_xyz[3 * o + 1] = a.list.xyz[3 * e[j] + 1];
                 a.out_xyz[3 * o + 2] = a.list.xyz[3 * e[j] + 2];
-                a.out_bgr[o] = a.list.bgr[e[j]];
+                // colour of the source pixel (:170, features.cpp:76-80): the tag names keyframe and pixel
+                a.out_bgr[o] = ldg_u32_unaligned(a.frames[tag[j] >> 32].bgr + 3ull * (uint32_t)tag[j]) & 0xFFFFFFu;
                 a.out_key[o] = key[j];
                 a.out_tag[o] = tag[j];
             }
