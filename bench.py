@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--workload", default="c2_500kf_640x480_1cm", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="override keyframes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-frames", type=int, default=48)
+    ap.add_argument("--cpu-sample-frames", type=int, default=500)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -242,7 +242,7 @@ def cpu_baseline(seq, n_sample, W, H, voxel, t_dist):
     t0 = time.perf_counter()
     c = oracle.fuse(frames, p, n_threads=threads)
     t_mt = time.perf_counter() - t0
-    n1 = max(1, n_sample // 4)
+    n1 = max(1, n_sample // 8)
     t0 = time.perf_counter()
     oracle.fuse(frames[:n1] if n1 == n_sample else seq.frame_dicts(0, n1), p, n_threads=1)
     t_1 = time.perf_counter() - t0

@@ -93,3 +93,26 @@ def test_c2_properties_at_scale():
     fine_parents = set(map(tuple, np.trunc(xyz / 20.0).astype(np.int64).tolist()))
     assert fine_parents <= have
     ctx.close()
+
+
+def test_c2_full_workload_against_oracle(fusion_path):
+    """The whole bench workload (BASELINE.json configs[1]: 500 keyframes 640x480, the generator and
+    seed bench.py uses), bit for bit against the oracle: 153.6 M pixels, 1.59 M points, ~5 s of oracle
+    time on the GPU box's 16 host threads.  Once (on the default path): the oracle run dominates."""
+    if fusion_path != "chain":
+        pytest.skip("full-size oracle run once, on the default path")
+    import torch
+    n = 500
+    seq = synth.make_sequence(n, 640, 480, K=(525.0, 525.0, 319.5, 239.5), device=torch.device("cuda", 0),
+                              seed=20240315, components=1, radius_m=0.8)
+    op, gp = both_params(voxel_size=10.0, T_dist=500.0)
+    ctx = _ctx_from_device_sequence(seq, gp, n)
+    ctx.run()
+    xyz, bgr, key, tag = ctx.read_points()
+    st = ctx.stats()
+    fb, fa = ctx.frame_counts()
+    ctx.close()
+    assert st["fused_chain"] == 1
+    want = oracle.fuse(seq.frame_dicts(0, n), op, n_threads=16)
+    assert want.key.shape[0] > 1500000
+    assert_same_cloud(dict(xyz=xyz, bgr=bgr, key=key, tag=tag, stats=st, frame_before=fb, frame_after=fa), want)
