@@ -120,6 +120,7 @@ struct sfm_fusion_ctx {
     DevBuf<unsigned int> d_qcount;     // [n_frames][kQueueShards*16] queue cursors
     uint32_t q_shard_cap = 0;
     int n_cu = 256;
+    bool chain_xcd = true;           // XCD-aware piece mapping (needs 256 CUs; SFM_CHAIN_XCD=0 selects the generic kernel)
     // one allocation: Counters | cursors | stat shards (zeroed by a single memset per run)
     unsigned char *d_small = nullptr;
     HostCounters *h_small = nullptr;  // pinned
@@ -533,7 +534,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             if (c->profile) HIP_TRY(c, hipEventRecord(c->kev[4 * g], sa));
             if (c->chain_coop) {
                 void *args[] = {(void *)&fr, (void *)&np, (void *)&ca};
-                const void *kern = c->n_cu == 256 ? (const void *)fuse_chain_kernel : (const void *)fuse_chain_kernel_any;
+                const void *kern = c->chain_xcd ? (const void *)fuse_chain_kernel : (const void *)fuse_chain_kernel_any;
                 if (hipLaunchCooperativeKernel(kern, dim3(c->n_cu), dim3(kChainThreads), args,
                                                (unsigned int)c->chain_lds, sa) != hipSuccess) {
                     // the runtime refuses the grid (fewer CUs available than the device reports):
@@ -545,7 +546,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
                     return SFM_OK;
                 }
             } else {
-                if (c->n_cu == 256)  // XCD-aware piece mapping (8 XCDs x 32 CUs)
+                if (c->chain_xcd)  // XCD-aware piece mapping (8 XCDs x 32 CUs)
                     hipLaunchKernelGGL(fuse_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa, fr, np, ca);
                 else
                     hipLaunchKernelGGL(fuse_chain_kernel_any, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa, fr, np, ca);
@@ -705,13 +706,17 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
         if (items >= 8 && (coop || !c->chain_coop)) {
             c->chain_items = items;
             c->chain_lds = chain_lds_bytes(items);
-            const void *kern = c->n_cu == 256 ? (const void *)fuse_chain_kernel : (const void *)fuse_chain_kernel_any;
-            if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->chain_lds) != hipSuccess) {
+            if (hipFuncSetAttribute((const void *)fuse_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)c->chain_lds) != hipSuccess ||
+                hipFuncSetAttribute((const void *)fuse_chain_kernel_any, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)c->chain_lds) != hipSuccess) {
                 (void)hipGetLastError();
                 c->chain_items = 0;
             }
         }
     }
+    c->chain_xcd = c->n_cu == 256;
+    if (const char *e = std::getenv("SFM_CHAIN_XCD")) c->chain_xcd = c->chain_xcd && std::atoi(e) != 0;
     if (const char *e = std::getenv("SFM_FUSE_CHAIN")) c->chain = std::atoi(e) != 0;
     if (const char *e = std::getenv("SFM_CHAIN_COOP")) c->chain_coop = std::atoi(e) != 0;
     if (const char *e = std::getenv("SFM_TABLE_THREADS")) {
