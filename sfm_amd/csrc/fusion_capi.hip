@@ -93,7 +93,12 @@ struct sfm_fusion_ctx {
     DevBuf<double> d_tables;         // x/y/covariance lookup tables
     DevBuf<FrameDev> d_nbrpack;      // per keyframe: a FrameDev copy of each filtered neighbour
     DevBuf<FrameDev> d_frames;       // every keyframe (fuse_chain_kernel reads them on the device)
-    DevBuf<unsigned int> d_bar;      // device-wide barrier words of fuse_chain_kernel
+    // one allocation, one memset per run: per-keyframe before/after counts, every group's barrier words of
+    // fuse_chain_kernel, the kernel pair's queue cursors (a fill per buffer was a dispatch each, ~7 us)
+    DevBuf<unsigned long long> d_zero;
+    unsigned long long *z_fbefore = nullptr, *z_fafter = nullptr;
+    unsigned int *z_bar = nullptr, *z_qcount = nullptr;
+    size_t z_bytes = 0;
     // keyframe chain: 1 = one persistent fuse_chain_kernel per group of keyframes (default when the
     // device can hold it), 0 = scan_frame_kernel + observe_frame_kernel per keyframe (SFM_FUSE_CHAIN)
     bool chain = true;
@@ -113,11 +118,10 @@ struct sfm_fusion_ctx {
     DevBuf<unsigned long long> d_list_key, d_list_tag, d_out_key, d_out_tag, d_cand;
     DevBuf<double> d_list_xyz, d_out_xyz;
     DevBuf<uint32_t> d_out_bgr;
-    DevBuf<unsigned long long> d_fbefore, d_fafter, d_group_end, d_cand_end;
+    DevBuf<unsigned long long> d_group_end, d_cand_end;
     uint64_t out_cap = 0;              // output slots of the last run (grown on kErrOutFull)
     DevBuf<uint32_t> d_qpix;           // survivor queue of the keyframe in flight
     DevBuf<double> d_qpw;
-    DevBuf<unsigned int> d_qcount;     // [n_frames][kQueueShards*16] queue cursors
     uint32_t q_shard_cap = 0;
     int n_cu = 256;
     bool chain_xcd = true;           // XCD-aware piece mapping (needs 256 CUs; SFM_CHAIN_XCD=0 selects the generic kernel)
@@ -294,7 +298,18 @@ int build_layout(sfm_fusion_ctx *c)
         if (f.selected) c->total_px += (uint64_t)f.W * f.H;
     int rc;
     if ((rc = ensure(c, c->d_masks, total))) return rc;
-    if ((rc = ensure(c, c->d_bar, kBarBytes / sizeof(unsigned int)))) return rc;
+    {
+        const size_t bar_words = (size_t)kBarStride * std::max<size_t>(1, (n + kGroup - 1) / kGroup);
+        const size_t q_words = n * kQueueShards * 16;
+        const size_t n2 = (2 * n + 31) / 32 * 32;  // barrier words start on a 256-byte boundary
+        const size_t words64 = n2 + (bar_words + 1) / 2 + (q_words + 1) / 2 + 8;
+        if ((rc = ensure(c, c->d_zero, words64))) return rc;
+        c->z_fbefore = c->d_zero.p;
+        c->z_fafter = c->d_zero.p + n;
+        c->z_bar = reinterpret_cast<unsigned int *>(c->d_zero.p + n2);
+        c->z_qcount = c->z_bar + (bar_words + 1) / 2 * 2;
+        c->z_bytes = words64 * sizeof(unsigned long long);
+    }
     std::vector<FrameDev> &fd = c->h_frames;
     fd.assign(n, FrameDev());
     std::vector<uint32_t> nbr;
@@ -353,9 +368,9 @@ int build_layout(sfm_fusion_ctx *c)
         if ((uint64_t)f.W * f.H == 0) {
             // an empty image is never visible and has no pixels, but the kernels' branch-free
             // gathers read element 0 of whatever they are given: give them readable memory
-            d.depth = reinterpret_cast<const uint16_t *>(c->d_bar.p);
-            d.bgr = reinterpret_cast<const uint8_t *>(c->d_bar.p);
-            d.mask = reinterpret_cast<uint8_t *>(c->d_bar.p);
+            d.depth = reinterpret_cast<const uint16_t *>(c->z_bar);
+            d.bgr = reinterpret_cast<const uint8_t *>(c->z_bar);
+            d.mask = reinterpret_cast<uint8_t *>(c->z_bar);
             d.xtab = c->d_tables.p;
             d.ytab = c->d_tables.p;
         }
@@ -380,8 +395,6 @@ int build_layout(sfm_fusion_ctx *c)
     if ((rc = ensure(c, c->d_nbrpack, pack.size()))) return rc;
     if ((rc = ensure(c, c->d_frames, n))) return rc;
     if (n) HIP_TRY(c, hipMemcpy(c->d_frames.p, fd.data(), n * sizeof(FrameDev), hipMemcpyHostToDevice));
-    if ((rc = ensure(c, c->d_fbefore, n))) return rc;
-    if ((rc = ensure(c, c->d_fafter, n))) return rc;
     if ((rc = ensure(c, c->d_group_end, (n + kGroup - 1) / kGroup * kListShards * 8))) return rc;
     if ((rc = ensure(c, c->d_cand_end, (n + kGroup - 1) / kGroup))) return rc;
     uint64_t max_tiles = 1;
@@ -389,7 +402,6 @@ int build_layout(sfm_fusion_ctx *c)
     c->q_shard_cap = (uint32_t)((max_tiles + kQueueShards - 1) / kQueueShards * kTile);
     if ((rc = ensure(c, c->d_qpix, (uint64_t)kQueueShards * c->q_shard_cap))) return rc;
     if ((rc = ensure(c, c->d_qpw, 3ull * kQueueShards * c->q_shard_cap))) return rc;
-    if ((rc = ensure(c, c->d_qcount, (uint64_t)n * kQueueShards * 16))) return rc;
     if (!pack.empty())
         HIP_TRY(c, hipMemcpy(c->d_nbrpack.p, pack.data(), pack.size() * sizeof(FrameDev), hipMemcpyHostToDevice));
     c->layout_dirty = false;
@@ -432,11 +444,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     if (c->d_masks.n) HIP_TRY(c, hipMemsetAsync(c->d_masks.p, 0, c->d_masks.n, sa));  // :40-45
     HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0xFF, table_cap * sizeof(Slot), sa));
     HIP_TRY(c, hipMemsetAsync(c->d_small, 0, kSmallBytes, sa));
-    if (n) {
-        HIP_TRY(c, hipMemsetAsync(c->d_fbefore.p, 0, n * sizeof(unsigned long long), sa));
-        HIP_TRY(c, hipMemsetAsync(c->d_fafter.p, 0, n * sizeof(unsigned long long), sa));
-        HIP_TRY(c, hipMemsetAsync(c->d_qcount.p, 0, n * kQueueShards * 16 * sizeof(unsigned int), sa));
-    }
+    HIP_TRY(c, hipMemsetAsync(c->d_zero.p, 0, c->z_bytes, sa));  // counts, barrier words, queue cursors
     HIP_TRY(c, hipEventRecord(c->ev_init, sa));
     HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_init, 0));
 
@@ -472,8 +480,8 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     t.table_mask = table_cap - 1;
     t.list = list;
     t.ctr = dev_ctr(c);
-    t.frame_before = c->d_fbefore.p;
-    t.frame_after = c->d_fafter.p;
+    t.frame_before = c->z_fbefore;
+    t.frame_after = c->z_fafter;
     t.cand = c->d_cand.p;
 
     FinalizeArgs fa;
@@ -504,16 +512,17 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     c->chain_ran = use_chain;
     for (size_t g = 0; g < n_groups; g++) {
         const size_t g0 = g * kGroup, g1 = std::min(n, g0 + kGroup);
+        bool group_event_recorded = false;
         if (use_chain) {
             // :48-52 for keyframes [g0, g1) in one launch; order is kept by the in-kernel barrier
             ChainArgs ca;
             ca.f0 = (uint32_t)g0;
             ca.f1 = (uint32_t)g1;
             ca.item_cap = c->chain_items;
-            ca.pad = 0;
+            ca.group = (uint32_t)g;
             ca.list = list;
             ca.stat = dev_stat(c);
-            ca.bar = c->d_bar.p;
+            ca.bar = c->z_bar + g * kBarStride;
             ca.P = a.P;
             const FrameDev *fr = c->d_frames.p;
             const FrameDev *np = c->d_nbrpack.p;
@@ -530,7 +539,6 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
                 c->stamp_n = (size_t)kGroup * c->n_cu * 16;
             }
 #endif
-            HIP_TRY(c, hipMemsetAsync(c->d_bar.p, 0, kBarBytes, sa));
             if (c->profile) HIP_TRY(c, hipEventRecord(c->kev[4 * g], sa));
             if (c->chain_coop) {
                 void *args[] = {(void *)&fr, (void *)&np, (void *)&ca};
@@ -546,10 +554,16 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
                     return SFM_OK;
                 }
             } else {
+                // the group's event rides on the dispatch itself: a separate event record is one more
+                // packet behind every launch, and the next launch waits ~8 us longer for it
+                hipEvent_t stop = c->profile ? nullptr : c->gev[g];
                 if (c->chain_xcd)  // XCD-aware piece mapping (8 XCDs x 32 CUs)
-                    hipLaunchKernelGGL(fuse_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa, fr, np, ca);
+                    hipExtLaunchKernelGGL(fuse_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa, nullptr,
+                                          stop, 0, fr, np, ca);
                 else
-                    hipLaunchKernelGGL(fuse_chain_kernel_any, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa, fr, np, ca);
+                    hipExtLaunchKernelGGL(fuse_chain_kernel_any, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa,
+                                          nullptr, stop, 0, fr, np, ca);
+                group_event_recorded = !c->profile;
             }
             if (c->profile) HIP_TRY(c, hipEventRecord(c->kev[4 * g + 1], sa));
         } else
@@ -558,7 +572,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             const uint64_t px = (uint64_t)f.W * f.H;
             if (!px) continue;
             const uint32_t nw = std::min<uint32_t>(std::max<uint32_t>(f.n_filtered, 1), c->max_waves);
-            q.count = c->d_qcount.p + i * kQueueShards * 16;
+            q.count = c->z_qcount + i * kQueueShards * 16;
             sc.F = c->h_frames[i];
             sc.q = q;
             sc.P = a.P;
@@ -594,10 +608,12 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             }
         }
         {
-            // list boundaries of the group: snapshot of the append cursors, in stream order
-            HIP_TRY(c, hipMemcpyAsync(c->d_group_end.p + g * kListShards * 8, dev_cursor(c),
-                                      kListShards * 8 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, sa));
-            HIP_TRY(c, hipEventRecord(c->gev[g], sa));
+            // list boundaries of the group: fuse_chain_kernel's last workgroup has written them; the kernel
+            // pair needs a snapshot of the append cursors, in stream order
+            if (!use_chain)
+                HIP_TRY(c, hipMemcpyAsync(c->d_group_end.p + g * kListShards * 8, dev_cursor(c),
+                                          kListShards * 8 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, sa));
+            if (!group_event_recorded) HIP_TRY(c, hipEventRecord(c->gev[g], sa));
             HIP_TRY(c, hipStreamWaitEvent(sb, c->gev[g], 0));
             t.f0 = (uint32_t)g0;
             t.f1 = (uint32_t)g1;
@@ -769,8 +785,8 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     release(c->d_part); release(c->d_gorder); release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
     release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_cand); release(c->d_list_xyz); release(c->d_out_xyz);
-    release(c->d_qpix); release(c->d_qpw); release(c->d_qcount); release(c->d_frames); release(c->d_bar);
-    release(c->d_out_bgr); release(c->d_fbefore); release(c->d_fafter); release(c->d_group_end); release(c->d_cand_end);
+    release(c->d_qpix); release(c->d_qpw); release(c->d_frames); release(c->d_zero);
+    release(c->d_out_bgr); release(c->d_group_end); release(c->d_cand_end);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto &e : c->ev)
@@ -919,7 +935,7 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
                                                          std::max<uint64_t>(c->total_px / 4, 1 << 16) / kListShards);
     uint64_t table_cap = fixed_tab ? pow2_at_least(c->prm.table_capacity)
                                    : pow2_at_least(std::max<uint64_t>(c->d_table.n,
-                                                                      std::max<uint64_t>(c->total_px / 8, 1 << 16)));
+                                                                      std::max<uint64_t>(c->total_px / 16, 1 << 16)));
     // output slots: what the previous run ended with, else one per 16 pixels (C2 needs one per 97, the
     // 5-mm C5 sample one per 21); the exact need is known after an overflowing run
     uint64_t out_cap = std::max<uint64_t>(c->out_cap, std::max<uint64_t>(c->total_px / 16, 1 << 12));
@@ -983,8 +999,8 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     c->fbefore.assign(n, 0);
     c->fafter.assign(n, 0);
     if (n) {
-        HIP_TRY(c, hipMemcpy(c->fbefore.data(), c->d_fbefore.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->fafter.data(), c->d_fafter.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->fbefore.data(), c->z_fbefore, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->fafter.data(), c->z_fafter, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     }
     st.n_acc = std::accumulate(c->fbefore.begin(), c->fbefore.end(), (uint64_t)0);
     st.global_before = std::accumulate(c->fafter.begin(), c->fafter.end(), (uint64_t)0);

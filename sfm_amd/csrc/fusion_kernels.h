@@ -116,7 +116,7 @@ struct ListDev {
     unsigned long long *cursor;     // [kListShards * 8]  (stride 8 => one line per cursor)
     // [n_groups][kListShards * 8]: copy of cursor[] taken on the keyframe stream after the last
     // keyframe of each group (a 1-KiB device-to-device copy), i.e. the groups' list boundaries
-    const unsigned long long *group_end;
+    unsigned long long *group_end;
 };
 
 // ---- exact arithmetic helpers ---------------------------------------------------------
@@ -745,12 +745,15 @@ constexpr int kBarSub = 16;                                      // first-level 
 constexpr unsigned long long kChainTimeoutTicks = 5000000ull;    // 50 ms of the 100-MHz clock
 // barrier words, one per 64-B line: sub[kBarSub], top, flag, abort
 constexpr int kBarTop = kBarSub * 16, kBarFlag = kBarTop + 16, kBarAbort = kBarFlag + 16;
-constexpr size_t kBarBytes = (size_t)(kBarAbort + 16) * sizeof(unsigned int);
+constexpr int kBarDone = kBarAbort + 16;  // workgroups that have left the kernel (the last one snapshots the list cursors)
+// one region per launch (keyframe group), all zeroed by one memset per run: no fill between the launches
+constexpr int kBarStride = (kBarDone + 16 + 63) / 64 * 64;
+constexpr size_t kBarBytes = (size_t)kBarStride * sizeof(unsigned int);
 
 struct ChainArgs {
     uint32_t f0, f1;           // keyframes [f0, f1) of this launch
     uint32_t item_cap;         // (chunk, neighbour) observation slots that fit in LDS
-    uint32_t pad;
+    uint32_t group;            // index of this launch's keyframe group (list.group_end row it writes)
     ListDev list;
     StatShard *stat;
     unsigned int *bar;
@@ -1335,6 +1338,17 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
             }
             // ... and do its mask-independent work
             chain_prepare<XCD8>(frames[f + 1], P, 0, w, lane, b, G, pre, err);
+        }
+    }
+    // The group's list boundaries for its table kernel: every workgroup's reservations have returned
+    // (thread 0 used their values), so the workgroup that leaves last sees the final cursors.  (A
+    // 1-KiB copy behind every launch cost a dispatch gap of ~10 us on the chain's stream.)
+    if (threadIdx.x == 0) {
+        const unsigned left = __hip_atomic_fetch_add(a.bar + kBarDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == G - 1u) {
+            unsigned long long *ge = a.list.group_end + (size_t)a.group * kListShards * 8;
+            for (int sh = 0; sh < kListShards; sh++)
+                ge[sh * 8] = __hip_atomic_load(a.list.cursor + sh * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     const unsigned any_err = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(err != 0) != 0ull));
