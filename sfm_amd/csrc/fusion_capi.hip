@@ -442,7 +442,8 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     hipStream_t sa = c->stream, sb = c->stream_b;
     HIP_TRY(c, hipEventRecord(c->ev[0], sa));
     if (c->d_masks.n) HIP_TRY(c, hipMemsetAsync(c->d_masks.p, 0, c->d_masks.n, sa));  // :40-45
-    HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0xFF, table_cap * sizeof(Slot), sa));
+    // the table is first touched by the first group's table kernel: its fill runs on stream B, under the first chain launch
+    HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0xFF, table_cap * sizeof(Slot), sb));
     HIP_TRY(c, hipMemsetAsync(c->d_small, 0, kSmallBytes, sa));
     HIP_TRY(c, hipMemsetAsync(c->d_zero.p, 0, c->z_bytes, sa));  // counts, barrier words, queue cursors
     HIP_TRY(c, hipEventRecord(c->ev_init, sa));
