@@ -3,11 +3,13 @@
 // computes needs a HIP device and fails with SFM_E_HIP otherwise.
 //
 // Stream plan of one run (DESIGN.md "Streams"):
-//   stream A (caller's or private): memsets, then scan_frame_kernel + observe_frame_kernel per keyframe, strictly in
-//            order -- the visibility masks make this a chain.
-//   stream B (private): table_group_kernel per group of 32 keyframes, each waiting on the event
-//            of the group's last keyframe kernel; it overlaps the chain on stream A.
-//   stream A then waits for B, and finalize_kernel compacts the winners.
+//   stream A (caller's or private): the fills of masks and counters, then one fuse_chain_kernel per group of 32
+//            keyframes (or scan_frame_kernel + observe_frame_kernel per keyframe), strictly in order -- the
+//            visibility masks make this a chain -- and nothing else between the launches.
+//   stream B (private): the table's fill, then table_group_kernel + finalize_kernel per group, each waiting on the
+//            event that rides on the group's chain launch; they overlap the chain on stream A.
+//   stream A then waits for B; one host synchronisation per run.
+//   upload stream (private): host images of sfm_fusion_add_keyframe, through two pinned staging buffers.
 #include "../../include/sfm_fusion.h"
 #include "fusion_kernels.h"
 #include <hip/hip_ext.h>

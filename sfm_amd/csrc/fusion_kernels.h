@@ -6,13 +6,19 @@
 // evaluation orders that matter are spelled out next to each function.
 //
 // Kernels:
+//   fuse_chain_kernel   (default) one persistent launch per group of <= 32 keyframes, one 1024-thread
+//                       workgroup per CU, a device-wide barrier between keyframes (the visibility
+//                       masks chain the keyframes); fuse_chain_kernel_any is the same
+//                       body without the XCD-aware pixel mapping, for grids other than 256.
 //   scan_frame_kernel, observe_frame_kernel
-//                       two launches per keyframe, in order (the visibility masks chain the
-//                       keyframes); see "the per-keyframe kernels" below.
+//                       the fallback: two launches per keyframe, in order; see "the per-keyframe
+//                       kernels" below.
 //   table_group_kernel  first-wins voxel filter for a group of <= 32 keyframes: open-addressing
 //                       hash in HBM, atomicCAS key claim + atomicMin order tag.  Runs on a
-//                       second stream, off the keyframe chain.
-//   finalize_kernel     gathers the winners into the output cloud.
+//                       second stream, beside the keyframe chain (<= 32 VGPRs: see build.sh).
+//   finalize_kernel     gathers a group's winners (and their colours) into the output cloud.
+//   partition_*, merge_*  multi-GPU exchange by voxel-key hash and the owners' reduce.
+//   iota_kernel, cloud_gather_kernel  the cloud in key order for sfm_fusion_read_points.
 #pragma once
 #ifndef SFM_OBSERVE_WAVES_PER_EU
 #define SFM_OBSERVE_WAVES_PER_EU 6
