@@ -198,3 +198,26 @@ def test_division_operands_outside_the_shared_range_fall_back_to_plain_division(
     g = _run_raw(frames, gp)
     assert g["stats"]["fused_chain"] == 0
     assert_same_cloud(g, want)
+
+
+def test_run_on_the_callers_stream():
+    """`stream` of sfm_fusion_create: the chain runs on a stream the caller owns (here a torch stream that is
+    not the default one); the library's second stream and its events hang off it."""
+    import torch
+    seq = synth.make_sequence(5, 96, 72, K=(196.8, 196.8, 47.5, 35.5), window=2)
+    frames = seq.frame_dicts()
+    op, gp = both_params(voxel_size=10.0, T_dist=500.0)
+    want = oracle.fuse(frames, op)
+    s = torch.cuda.Stream()
+    ctx = fusion.FusionContext(gp, 0, s.cuda_stream)
+    for f in frames:
+        ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+    for i, f in enumerate(frames):
+        ctx.set_neighbors(i, f["nbrs"])
+    for _ in range(2):
+        ctx.run()
+        xyz, bgr, key, tag = ctx.read_points()
+        assert np.array_equal(key, want.key) and np.array_equal(tag, want.tag) and np.array_equal(bgr, want.bgr)
+        assert np.array_equal(xyz.view(np.uint64), want.xyz.view(np.uint64))
+    ctx.close()
+    s.synchronize()
