@@ -1171,8 +1171,12 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
             }
 #endif
 #pragma unroll
-            for (int u = 0; u < kChainSegs; u++)
-                mv[u] = mask_load_coherent(F.mask + (pre.cand[u] ? pre.pixel[u] : 0u));
+            for (int u = 0; u < kChainSegs; u++) {
+                // only lanes with a candidate pixel ask: a default address would make one mask byte the target
+                // of every idle lane of every workgroup, and these loads go past the L2 to the memory side
+                mv[u] = 255u;
+                if (pre.cand[u]) mv[u] = mask_load_coherent(F.mask + pre.pixel[u]);
+            }
 #pragma unroll
             for (int u = 0; u < kChainSegs; u++) {
                 const bool pass = pre.cand[u] && (mv[u] == 0u) && (part == 0 || part == (uint32_t)u + 1);  // :100
