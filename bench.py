@@ -220,7 +220,13 @@ def main():
                   "load_factor": st["table_used"] / max(1, st["table_capacity"]),
                   "max_probe": st["max_probe"]},
         "counters": {k: st[k] for k in ("n_px", "n_gather", "n_acc", "n_hit", "n_vox")},
+        # 1/0: the persistent chain kernel ran; fallbacks > 0: a device-wide barrier timed out (another process held
+        # CUs) and the timed runs went through the slower kernel pair -- such a line is NOT the path's figure
+        "chain": {"fused_chain": st["fused_chain"], "fallbacks": st["chain_fallbacks"]},
     }
+    if st["chain_fallbacks"] or (not st["fused_chain"] and os.environ.get("SFM_FUSE_CHAIN", "1") != "0"):
+        out["data"] += " (FALLBACK: the kernel pair ran instead of the chain kernel; not the path's figure)"
+        print("bench.py: the persistent chain kernel fell back to the kernel pair", file=sys.stderr, flush=True)
 
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, min(args.cpu_sample_frames, n_kf), W, H, voxel, t_dist)
@@ -232,13 +238,28 @@ def main():
         dist.destroy_process_group()
 
 
+def host_threads():
+    """(threads the CPU baseline uses, CPUs the machine reports).  The threads are every CPU this process may use:
+    its affinity mask, bounded by OMP_NUM_THREADS when the box sets it (a GPU box hands each GPU's job a share
+    of the machine and says so there; os.cpu_count() reports the whole machine)."""
+    host_cpus = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = host_cpus
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) >= 1:
+        avail = min(avail, int(share))
+    return max(1, avail), host_cpus
+
+
 def cpu_baseline(seq, n_sample, W, H, voxel, t_dist):
     """Times the CPU oracle (a restatement of the reference, kind "port") on the first
     n_sample keyframes of the same workload, on this box's host cores."""
     from oracle import oracle
     frames = seq.frame_dicts(0, n_sample)
     p = oracle.default_params(voxel_size=voxel, T_dist=t_dist)
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads, host_cpus = host_threads()
     t0 = time.perf_counter()
     c = oracle.fuse(frames, p, n_threads=threads)
     t_mt = time.perf_counter() - t0
@@ -250,6 +271,7 @@ def cpu_baseline(seq, n_sample, W, H, voxel, t_dist):
         "value": n_sample * W * H / t_mt,
         "unit": "px/s",
         "cores": threads,
+        "host_cpus": host_cpus,
         "kind": "port",
         "sample": f"first {n_sample} keyframes of the workload, pixel loop over {threads} host threads "
                   f"(mirrors the reference's par_unseq loop); single-thread figure on the first {n1}",

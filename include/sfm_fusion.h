@@ -85,6 +85,9 @@ typedef struct sfm_fusion_stats {
     double fuse_kernel_sum_ms;       /* sum of their durations */
     double scan_kernel_sum_ms;       /* sum of the scan_frame_kernel durations (0 with fuse_chain_kernel) */
     uint64_t fused_chain;            /* 1: the persistent fuse_chain_kernel ran; 0: the scan+observe pair */
+    uint64_t chain_fallbacks;        /* runs of this ctx that a device-wide barrier timeout (CUs held by someone
+                                      * else) sent from fuse_chain_kernel to the kernel pair; the next 8 runs stay
+                                      * on the pair, the third fallback is permanent */
 } sfm_fusion_stats;
 
 void sfm_fusion_default_params(sfm_fusion_params *p);

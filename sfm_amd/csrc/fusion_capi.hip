@@ -66,10 +66,8 @@ struct sfm_fusion_ctx {
     int device = 0;
     hipStream_t stream = nullptr;    // stream A
     hipStream_t stream_b = nullptr;  // stream B (table kernels)
-#if SFM_STAMPS
-    unsigned long long *stamp_ptr = nullptr;
+    unsigned long long *stamp_ptr = nullptr;  // -DSFM_STAMPS=1 builds: timestamps of one chain launch
     size_t stamp_n = 0;
-#endif
     bool own_stream = false;
     std::vector<HostFrame> frames;
     bool layout_dirty = true;
@@ -99,7 +97,7 @@ struct sfm_fusion_ctx {
     // fuse_chain_kernel, the kernel pair's queue cursors (a fill per buffer was a dispatch each, ~7 us)
     DevBuf<unsigned long long> d_zero;
     unsigned long long *z_fbefore = nullptr, *z_fafter = nullptr;
-    unsigned int *z_bar = nullptr, *z_qcount = nullptr;
+    unsigned int *z_bar = nullptr, *z_qcount = nullptr, *z_abort = nullptr;
     size_t z_bytes = 0;
     // keyframe chain: 1 = one persistent fuse_chain_kernel per group of keyframes (default when the
     // device can hold it), 0 = scan_frame_kernel + observe_frame_kernel per keyframe (SFM_FUSE_CHAIN)
@@ -113,7 +111,9 @@ struct sfm_fusion_ctx {
     uint32_t chain_items = 0;        // (chunk, neighbour) LDS slots; 0 = chain kernel unusable here
     size_t chain_lds = 0;
     bool chain_ran = false;
-    uint32_t chain_fallbacks = 0;    // times a barrier timeout sent this ctx back to the kernel pair
+    uint32_t chain_fallbacks = 0;    // runs that a barrier timeout (or a division-range error) sent to the kernel pair
+    uint32_t chain_off_runs = 0;     // after a fallback: runs left on the kernel pair before the chain kernel is tried again
+    unsigned long long chain_timeout_ticks = kChainTimeoutTicks;  // SFM_CHAIN_TIMEOUT_TICKS (tests force a timeout with it)
     std::vector<FrameDev> h_frames;  // device-side description of every keyframe (host copy)
     DevBuf<uint8_t> d_masks;
     DevBuf<Slot> d_table;
@@ -310,6 +310,7 @@ int build_layout(sfm_fusion_ctx *c)
         c->z_fafter = c->d_zero.p + n;
         c->z_bar = reinterpret_cast<unsigned int *>(c->d_zero.p + n2);
         c->z_qcount = c->z_bar + (bar_words + 1) / 2 * 2;
+        c->z_abort = reinterpret_cast<unsigned int *>(c->d_zero.p + words64 - 8);  // the slack words at the end
         c->z_bytes = words64 * sizeof(unsigned long long);
     }
     std::vector<FrameDev> &fd = c->h_frames;
@@ -527,13 +528,16 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             ca.stat = dev_stat(c);
             ca.bar = c->z_bar + g * kBarStride;
             ca.P = a.P;
+            ca.abort_all = c->z_abort;
+            ca.timeout_ticks = c->chain_timeout_ticks;
+            ca.stamps = nullptr;
             const FrameDev *fr = c->d_frames.p;
             const FrameDev *np = c->d_nbrpack.p;
 #if SFM_STAMPS
-            ca.stamps = nullptr;
             static unsigned long long *d_cstamps = nullptr;
             const char *sg = std::getenv("SFM_STAMP_GROUP");
-            if (sg && (size_t)std::atoi(sg) == g) {
+            const bool stamp_this = sg && (size_t)std::atoi(sg) == g && c->chain_xcd && !c->chain_coop;
+            if (stamp_this) {
                 const size_t bytes = (size_t)kGroup * c->n_cu * 16 * 8;
                 if (!d_cstamps) (void)hipMalloc(&d_cstamps, bytes);
                 (void)hipMemsetAsync(d_cstamps, 0, bytes, sa);
@@ -541,6 +545,9 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
                 c->stamp_ptr = d_cstamps;
                 c->stamp_n = (size_t)kGroup * c->n_cu * 16;
             }
+#else
+            const bool stamp_this = false;
+            (void)stamp_this;
 #endif
             if (c->profile) HIP_TRY(c, hipEventRecord(c->kev[4 * g], sa));
             if (c->chain_coop) {
@@ -560,6 +567,12 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
                 // the group's event rides on the dispatch itself: a separate event record is one more
                 // packet behind every launch, and the next launch waits ~8 us longer for it
                 hipEvent_t stop = c->profile ? nullptr : c->gev[g];
+#if SFM_STAMPS
+                if (stamp_this)
+                    hipExtLaunchKernelGGL(fuse_chain_kernel_stamps, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa,
+                                          nullptr, stop, 0, fr, np, ca);
+                else
+#endif
                 if (c->chain_xcd)  // XCD-aware piece mapping (8 XCDs x 32 CUs)
                     hipExtLaunchKernelGGL(fuse_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), c->chain_lds, sa, nullptr,
                                           stop, 0, fr, np, ca);
@@ -588,18 +601,6 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             const uint32_t resident = (uint32_t)c->n_cu * std::max<uint32_t>(1, c->waves_per_cu / nw);
             const uint32_t wgs = (uint32_t)std::min<uint64_t>((px + kWave - 1) / kWave, resident);
             const size_t lds = fuse_lds_bytes(f.n_filtered);
-#if SFM_STAMPS
-            a.stamps = nullptr;
-            static unsigned long long *d_stamps = nullptr;
-            const char *sf = std::getenv("SFM_STAMP_FRAME");
-            if (sf && (size_t)std::atoi(sf) == i) {
-                if (!d_stamps) (void)hipMalloc(&d_stamps, (size_t)8192 * 8 * 8 * 8);
-                (void)hipMemsetAsync(d_stamps, 0, (size_t)8192 * 8 * 8 * 8, sa);
-                a.stamps = d_stamps;
-                c->stamp_ptr = d_stamps;
-                c->stamp_n = (size_t)wgs * nw * 8;
-            }
-#endif
             if (c->profile) {
                 hipExtLaunchKernelGGL(scan_frame_kernel, dim3(tiles), dim3(kWave), 0, sa, c->kev[4 * i],
                                       c->kev[4 * i + 1], 0, sc);
@@ -732,7 +733,20 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
                 (void)hipGetLastError();
                 c->chain_items = 0;
             }
+            // the device-wide barrier needs all n_cu workgroups resident at once: ask the runtime whether one
+            // workgroup of this size and LDS fits a CU at all (a plain launch performs no such check)
+            int per_cu = 0;
+            if (c->chain_items &&
+                (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fuse_chain_kernel, kChainThreads,
+                                                              c->chain_lds) != hipSuccess || per_cu < 1)) {
+                (void)hipGetLastError();
+                c->chain_items = 0;
+            }
         }
+    }
+    if (const char *e = std::getenv("SFM_CHAIN_TIMEOUT_TICKS")) {
+        const long long v = std::atoll(e);
+        if (v >= 1) c->chain_timeout_ticks = (unsigned long long)v;
     }
     c->chain_xcd = c->n_cu == 256;
     if (const char *e = std::getenv("SFM_CHAIN_XCD")) c->chain_xcd = c->chain_xcd && std::atoi(e) != 0;
@@ -892,7 +906,23 @@ int sfm_fusion_set_covisibility(sfm_fusion_ctx *c, const uint32_t *edge_a, const
         f.nbrs.clear();
         f.selected = false;
     }
+    // The first insertion of an edge wins in the reference and freezes its count (covisibility_insert,
+    // map.cpp:108-119; edges are keyed by the unordered pair, map.cpp:354-363): a repeated pair, in either
+    // direction, is ignored -- whatever count it carries.
+    std::vector<uint64_t> seen;
+    seen.reserve(n_edges);
     for (uint64_t e = 0; e < n_edges; e++) {
+        const uint32_t lo = std::min(edge_a[e], edge_b[e]), hi = std::max(edge_a[e], edge_b[e]);
+        seen.push_back(((uint64_t)lo << 32) | hi);
+    }
+    std::vector<uint64_t> order(n_edges);
+    std::iota(order.begin(), order.end(), (uint64_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return seen[x] < seen[y]; });
+    std::vector<bool> first(n_edges, false);
+    for (uint64_t i = 0; i < n_edges; i++)
+        if (i == 0 || seen[order[i]] != seen[order[i - 1]]) first[order[i]] = true;  // stable: smallest index of the pair
+    for (uint64_t e = 0; e < n_edges; e++) {
+        if (!first[e]) continue;
         HostFrame &fa = c->frames[edge_a[e]], &fb = c->frames[edge_b[e]];
         if (edge_count[e] >= select_min) fa.selected = fb.selected = true;  // dense_reconstruction.cpp:32-38
         if (edge_count[e] > neighbor_min) {                                 // map.cpp:157
@@ -901,10 +931,8 @@ int sfm_fusion_set_covisibility(sfm_fusion_ctx *c, const uint32_t *edge_a, const
         }
     }
     for (auto &f : c->frames) {
-        // canonical neighbour order: ascending keyframe index; the first insertion of
-        // an edge wins in the reference (map.cpp:108-119), so a repeated pair counts once
+        // canonical neighbour order: ascending keyframe index
         std::sort(f.nbrs.begin(), f.nbrs.end());
-        f.nbrs.erase(std::unique(f.nbrs.begin(), f.nbrs.end()), f.nbrs.end());
         if (!f.selected) f.nbrs.clear();
     }
     c->layout_dirty = true;
@@ -930,6 +958,10 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     }
     if (c->layout_dirty && (rc = build_layout(c))) return rc;
     c->have_result = false;
+    c->part_counts.clear();  // sfm_fusion_export_records needs counts of THIS run's cloud
+    // a fallback is not for life: after kChainRetryRuns runs on the kernel pair the chain kernel is tried again
+    // (three fallbacks in a ctx's life make it permanent: something else owns CUs of this device for good)
+    if (!c->chain && c->chain_off_runs > 0 && --c->chain_off_runs == 0 && c->chain_fallbacks < 3) c->chain = true;
     const bool fixed_tab = c->prm.table_capacity != 0, fixed_list = c->prm.max_points != 0;
     // Sizes: explicit, else what the previous run ended with, else a first guess that the
     // retry loop below doubles until the run fits.
@@ -957,6 +989,7 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
             if (!c->chain) return fail(c, SFM_E_HIP, "device-wide barrier timed out");
             c->chain = false;
             c->chain_fallbacks++;
+            c->chain_off_runs = 8;
             continue;
         }
         if (err & kErrKeyRange)
@@ -1016,6 +1049,7 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     st.fuse_kernel_sum_ms = 0;
     st.scan_kernel_sum_ms = 0;
     st.fused_chain = c->chain_ran ? 1 : 0;
+    st.chain_fallbacks = c->chain_fallbacks;
     if (c->profile && c->chain_ran) {
         for (size_t g = 0; g < (n + kGroup - 1) / kGroup; g++) {
             HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * g], c->kev[4 * g + 1]));

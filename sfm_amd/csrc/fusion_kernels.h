@@ -28,20 +28,8 @@
 #else
 #define SFM_OBSERVE_OCC
 #endif
-#ifndef SFM_ABLATE
-#define SFM_ABLATE 0  // diagnostic builds only: removes one cost of fuse_chain_kernel's step B (results are wrong)
-#endif
-#ifndef SFM_BARRIER
-#define SFM_BARRIER 0  // 0: two-level counters + flag; 1: one counter everybody adds to and polls; 2: 16 counters, everybody polls all
-#endif
-#ifndef SFM_REPEAT_ABL
-#define SFM_REPEAT_ABL 0  // with SFM_REPEAT == 1: what the second (discarded) pass of step B leaves out
-#endif
-#ifndef SFM_REPEAT
-#define SFM_REPEAT 0  // diagnostic builds only: 1/2/3 run step B / the step-C fusion / the step-C scatter twice (same results)
-#endif
 #ifndef SFM_STAMPS
-#define SFM_STAMPS 0  // diagnostic build only (tools_stamps.sh): per-wave phase timestamps of one launch
+#define SFM_STAMPS 0  // diagnostic build only (tools/chain_stamps.py): adds fuse_chain_kernel_stamps, thread-0 phase timestamps of one launch
 #endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -466,22 +454,7 @@ struct FuseArgs {
     ListDev list;
     StatShard *stat;           // [kStatShards]
     DevParams P;
-#if SFM_STAMPS
-    unsigned long long *stamps;  // [gridDim.x * waves][8] 100-MHz timestamps, or nullptr
-#endif
 };
-
-#if SFM_STAMPS
-#define SFM_STAMP(i)                                                                               \
-    do {                                                                                           \
-        if (a.stamps && lane == 0 && first_chunk)                                                  \
-            a.stamps[((size_t)blockIdx.x * NW + w) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();   \
-    } while (0)
-#define SFM_STAMP_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
-#else
-#define SFM_STAMP(i) do {} while (0)
-#define SFM_STAMP_WAIT() do {} while (0)
-#endif
 
 // One re-observation, split at its two memory round trips so that observe_frame_kernel can keep
 // two neighbours in flight per wave.
@@ -555,10 +528,6 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
     const FrameDev &F = a.F;
     const DevParams &P = a.P;
     const uint32_t K = F.nbr_count;
-#if SFM_STAMPS
-    bool first_chunk = true;
-#endif
-    SFM_STAMP(0);
     double *s_obs = reinterpret_cast<double *>(smem);
     uint32_t *s_hit = reinterpret_cast<uint32_t *>(s_obs + (size_t)K * 256);
     unsigned long long *s_kept = reinterpret_cast<unsigned long long *>(s_hit + (size_t)K * 64);
@@ -573,7 +542,6 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
 #pragma unroll
     for (int s = 0; s < kQueueShards; s++) max_cnt = max(max_cnt, a.q.count[s * 16]);
     const uint32_t total_chunks = ((max_cnt + kWave - 1) / kWave) * kQueueShards;
-    SFM_STAMP(1);
     for (uint32_t c = blockIdx.x; c < total_chunks; c += gridDim.x) {
         const uint32_t shard = c % kQueueShards, j = c / kQueueShards;
         const uint32_t cnt_s = a.q.count[shard * 16];
@@ -594,8 +562,6 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
             if (lane == 0) base_r = atomicAdd(&a.list.cursor[(c % kListShards) * 8], (unsigned long long)n_in);
             if (act) pix = pix_q;
         }
-        SFM_STAMP_WAIT();
-        SFM_STAMP(2);
         // wave w re-observes the chunk in neighbours w, w+NW, ...  (:187-216), two at a time:
         // both projections, then both depth gathers, then both table reads are in flight
         // together (branch-free; a lane without a visible projection reads element 0)
@@ -633,10 +599,7 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
                 }
             }
         }
-        SFM_STAMP_WAIT();
-        SFM_STAMP(3);
         __syncthreads();
-        SFM_STAMP(4);
         // every wave: the decision (:218, :229) from the ballots ...
         unsigned n_obs = 0, n_close = 0;
         for (uint32_t k = 0; k < K; k++) {
@@ -653,7 +616,6 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
             if (hitk && nbp[k].order > F.order)
                 *(__attribute__((address_space(1))) uint8_t *)(nbp[k].mask + s_hit[k * 64 + lane]) = 255;
         }
-        SFM_STAMP(5);
         // one wave: weighted fusion in neighbour order (:157-165), voxel key, record
         if (w == p3) {
             // the sums run in neighbour order; the LDS reads do not depend on them and are issued
@@ -710,11 +672,6 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
                 }
             }
         }
-        SFM_STAMP_WAIT();
-        SFM_STAMP(6);
-#if SFM_STAMPS
-        first_chunk = false;
-#endif
         if (c + gridDim.x < total_chunks) __syncthreads();  // LDS is reused by the next chunk
     }
     if (lane == 0 && (c_gather | c_hit)) {
@@ -740,7 +697,24 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
 // gfx950) and ordered by "wait until my stores are acknowledged, then arrive at the barrier":
 // no L2 write-back/invalidate is needed, which is what makes the barrier (about 2 us for 256
 // workgroups, tools/barrier_bench.hip) cheaper than a kernel boundary.  Every spin is bounded:
-// a workgroup that waits longer than kChainTimeoutTicks raises the abort flag and all leave.
+// a workgroup that waits longer than the launch's timeout raises the abort flags and all leave.
+//
+// Why relaxed atomics suffice here (no release/acquire pair).  In the AMDGPU memory model for gfx942/gfx950
+// (LLVM AMDGPUUsage, "Memory Model gfx942") an agent-scope release is `buffer_wbl2 sc1; s_waitcnt vmcnt(0)`
+// and an agent-scope acquire is `s_waitcnt vmcnt(0); buffer_inv sc1`: the write-back and the invalidate exist
+// for bytes that PLAIN stores left dirty in an XCD's L2 and that PLAIN loads may find stale in a CU's L1.
+// Agent-scope atomic stores and loads are `global_store/load ... sc1`: the store is written through past the
+// XCD's L2 and its vmcnt slot is released when the write is acknowledged; the load bypasses L1 and the
+// non-coherent L2 lines.  Every access to a mask byte inside this kernel is such an atomic, so what is left of
+// the release is the wait, and nothing is left of the acquire.  That is MI355X_MICROARCH.md's valid form
+// "sc1 loads in place of the acquire" (section "Workgroup dispatch, XCD placement & inter-workgroup
+// visibility"), whose conditions hold: (1) every load of a mask byte in this kernel is mask_load_coherent,
+// (2) every store is mask_store_coherent, (3) every wave waits `s_waitcnt vmcnt(0)` (inline asm: the compiler
+// cannot drop it) after its stores and the workgroup's one arriving lane adds behind a workgroup barrier,
+// (4) the signal is an agent-scope atomic add by one lane per workgroup, the last adder raises sc1 flags, the
+// consumer polls one flag with sc1 loads and its other waves load behind a workgroup barrier.  The guide's
+// measured rows cover 2- to 16-byte accesses; the 1-byte accesses used here are covered by this repository's own
+// bit-exact runs (tests/test_gpu_fullsize.py: 153.6 M pixels, every mask byte decides a point's membership).
 
 constexpr int kChainWaves = 16;
 constexpr int kChainThreads = kChainWaves * kWave;
@@ -770,25 +744,22 @@ struct ChainArgs {
     StatShard *stat;
     unsigned int *bar;
     DevParams P;
-#if SFM_STAMPS
-    unsigned long long *stamps;  // [f1 - f0][gridDim.x][16] 100-MHz timestamps of thread 0, or nullptr
-#endif
+    unsigned int *abort_all;            // ctx-wide: set by the first barrier timeout of a run, later launches leave at once
+    unsigned long long timeout_ticks;   // barrier spin limit in 100-MHz ticks
+    unsigned long long *stamps;  // diagnostic instantiation only: [f1 - f0][gridDim.x][16] 100-MHz timestamps of thread 0
 };
 
-#if SFM_REPEAT == 5
-#define CHAIN_EPOCH_ARRIVE(i) (2 * (i) + 1)
-#else
-#define CHAIN_EPOCH_ARRIVE(i) ((i) + 1)
-#endif
-#if SFM_STAMPS
-#define SFM_CSTAMP(i)                                                                              \
-    do {                                                                                           \
-        if (a.stamps && threadIdx.x == 0)                                                          \
-            a.stamps[((size_t)(f - a.f0) * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#else
-#define SFM_CSTAMP(i) do {} while (0)
-#endif
+// Phase timestamps of thread 0 (tools/chain_stamps.py); compiled into the diagnostic instantiation only
+// (fuse_chain_kernel_stamps, -DSFM_STAMPS=1 builds): the production kernels carry none of it.
+template <bool STAMPS>
+__device__ __forceinline__ void chain_stamp(const ChainArgs &a, uint32_t f, int i, unsigned long long v = ~0ull)
+{
+    if (STAMPS) {
+        if (a.stamps && threadIdx.x == 0)
+            a.stamps[((size_t)(f - a.f0) * gridDim.x + blockIdx.x) * 16 + i] = v == ~0ull ? __builtin_amdgcn_s_memrealtime() : v;
+    }
+}
+#define SFM_CSTAMP(i) chain_stamp<STAMPS>(a, f, (i))
 
 // Host: may fuse_chain_kernel's unchecked shared-reciprocal divisions be used for this keyframe?
 // (1) cov_trace_vals: operands (-u*b), (-v*b) for 1 <= u < W, 1 <= v < H (zero passes) and disparity^2
@@ -830,15 +801,6 @@ __device__ __forceinline__ unsigned bar_load(const unsigned int *p)
 // thread 0 of every workgroup, once per keyframe; the caller has waited for its own stores
 __device__ __forceinline__ void chain_arrive(unsigned int *bar, unsigned G, unsigned epoch)
 {
-#if SFM_BARRIER == 1
-    (void)G; (void)epoch;
-    (void)__hip_atomic_fetch_add(bar + kBarTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-#elif SFM_BARRIER == 2
-    (void)G; (void)epoch;
-    (void)__hip_atomic_fetch_add(bar + (blockIdx.x % kBarSub) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-#endif
     const unsigned s = blockIdx.x % kBarSub;
     const unsigned members = G / kBarSub + (s < G % kBarSub ? 1u : 0u);
     const unsigned prev = __hip_atomic_fetch_add(bar + s * kBarSubSpace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -855,29 +817,23 @@ __device__ __forceinline__ void chain_arrive(unsigned int *bar, unsigned G, unsi
 
 __device__ __forceinline__ unsigned chain_progress(const unsigned int *bar, unsigned G)
 {
-#if SFM_BARRIER == 1
-    return bar_load(bar + kBarTop) / G;
-#elif SFM_BARRIER == 2
-    unsigned sum = 0;
-#pragma unroll
-    for (int i = 0; i < kBarSub; i++) sum += bar_load(bar + i * 16);
-    return sum / G;
-#else
     (void)G;
     return bar_load(bar + kBarFlagX + (blockIdx.x % (unsigned)kBarFlags) * kBarFlagSpace);
-#endif
 }
 
-__device__ __forceinline__ bool chain_wait(unsigned int *bar, unsigned epoch, unsigned G)
+__device__ __forceinline__ bool chain_wait(unsigned int *bar, unsigned epoch, unsigned G, unsigned long long timeout_ticks,
+                                           unsigned int *abort_all)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned spins = 0;
     while (chain_progress(bar, G) < epoch) {
         __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 31u) == 0u) {
+        if ((++spins & 31u) == 0u || timeout_ticks < 64ull) {
             if (bar_load(bar + kBarAbort) != 0u) return false;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > kChainTimeoutTicks) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
                 __hip_atomic_store(bar + kBarAbort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the launches still queued behind this one read this word on entry and leave at once
+                __hip_atomic_store(abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
         }
@@ -995,7 +951,7 @@ template <bool UNI>
 __device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, const DevParams &P, uint32_t K, uint32_t rc,
                                             uint32_t c0, uint32_t n, unsigned w, unsigned lane, const double *s_pw,
                                             double *s_obs, uint32_t *s_hit, unsigned long long *s_kept,
-                                            unsigned int *cnt_now, unsigned &c_gather, bool count, unsigned &err)
+                                            unsigned int *cnt_now, unsigned &c_gather, unsigned &err)
 {
     constexpr uint32_t kMaxIt = kChainMaxItems / kChainWaves;
     bool bad = false;
@@ -1016,9 +972,6 @@ __device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, co
         double2 e1a = make_double2(0, 0), e1b = make_double2(0, 0);
         if (t >= 1 && t <= kMaxIt) {
             const double *e = nbp[k1].ctab + 4 * (size_t)draw1;
-#if SFM_REPEAT_ABL & 1
-            if (!count) e = nbp[k1].ctab + 4 * (size_t)(1000u + lane);
-#endif
             e1a = ldg2(e);
             e1b = ldg2(e + 2);
         }
@@ -1047,9 +1000,6 @@ __device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, co
         uint32_t draw0 = 0;
         double x0 = 0, y0 = 0;
         if (t < kMaxIt) {
-#if SFM_REPEAT_ABL & 2
-            if (!count) { p0.npix = lane; p0.ix = (int)lane; p0.iy = (int)lane; }
-#endif
             draw0 = ldg(L.depth + p0.npix);  // :193 (no d>0 test)
             x0 = ldg(L.xtab + p0.ix);
             y0 = ldg(L.ytab + p0.iy);
@@ -1059,25 +1009,14 @@ __device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, co
             const uint32_t it = c2 * K + k2;
             const uint32_t si = min((c0 + c2) * kWave + lane, (uint32_t)kChainSurv - 1);
             bool kept, close;
-#if SFM_REPEAT_ABL & 4
-            if (!count) {  // no S3 arithmetic at all
-                asm volatile("" ::"v"(draw2), "v"(x2), "v"(y2), "v"(e2a.x), "v"(e2b.y));
-            } else
-#endif
-            {
-            ObsProj pq = p2;
-#if SFM_REPEAT == 1 && !(SFM_REPEAT_ABL & 8)
-            if (!count) pq.vis = false;  // the discarded pass computes, but keeps nothing and writes nothing
-#endif
             bool bd = false;
-            obs_finish<true>(nbp[k2], P, pq, draw2, x2, y2, e2a, e2b, s_pw[si], s_pw[kChainSurv + si], s_pw[2 * kChainSurv + si],
+            obs_finish<true>(nbp[k2], P, p2, draw2, x2, y2, e2a, e2b, s_pw[si], s_pw[kChainSurv + si], s_pw[2 * kChainSurv + si],
                        s_obs + (size_t)it * 256 + lane, s_hit + it * 64 + lane, kept, close, bd);
             bad = bad || (bd && p2.vis);  // an invisible lane's gathers read element 0
             const unsigned long long mk = __ballot(kept);
-            if (count) c_gather += (unsigned)__popcll(__ballot(p2.vis));
-            if (kept && count) atomicAdd(&cnt_now[c2 * kWave + lane], close ? 0x10001u : 1u);
-            if (lane == 0 && count) s_kept[it] = mk;
-            }
+            c_gather += (unsigned)__popcll(__ballot(p2.vis));
+            if (kept) atomicAdd(&cnt_now[c2 * kWave + lane], close ? 0x10001u : 1u);
+            if (lane == 0) s_kept[it] = mk;
         }
         p2 = p1; c2 = c1; k2 = k1; v2 = v1; draw2 = draw1; x2 = x1; y2 = y1; e2a = e1a; e2b = e1b;
         p1 = p0; c1 = cc0; k1 = k0; v1 = v0; draw1 = draw0; x1 = x0; y1 = y0;
@@ -1087,11 +1026,11 @@ __device__ __forceinline__ void chain_items(const FrameDev *__restrict__ nbp, co
 
 // frames = every keyframe in processing order, nbrpack = FrameDev copies of the filtered neighbours
 // (frames[i].nbr_begin ...); neither is written by any kernel.
-// Keep this kernel at or below 120 VGPRs (tools_isa_stats.py; __graft_entry__.build() checks it): with 4
+// Keep this kernel at or below 120 VGPRs (tools/isa_stats.py; __graft_entry__.build() checks it): with 4
 // waves per SIMD that leaves 32 of the 512 registers per lane for a wave of the table kernel of the
 // previous group.  At 121+ the allocation is 128, the CU is full, the chain workgroups cannot be placed
 // before that kernel has drained, and every launch loses its ~200 us.
-template <bool XCD8>
+template <bool XCD8, bool STAMPS>
 __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ frames,
                                                 const FrameDev *__restrict__ nbrpack, const ChainArgs &a)
 {
@@ -1112,26 +1051,22 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_nbmask + kMaxK);   // [2][kChainWaves][64]
     unsigned int *s_misc = s_cnt + 2 * kChainWaves * kWave;                     // [0] survivors, [1] go
     unsigned c_gather = 0, c_hit = 0, err = 0;
+    // an earlier launch of this run timed out at a barrier (the run is discarded and redone on the kernel pair): every
+    // workgroup of every later launch sees the word set -- it was written before this launch began -- and leaves
+    // (it still takes part in the list-boundary snapshot below, so that the group's table kernel walks an empty slice)
+    const bool aborted = bar_load(a.abort_all) != 0u;
+    if (aborted) err |= kErrBarrier;
     for (unsigned i = threadIdx.x; i < 2u * kChainWaves * kWave; i += kChainThreads) s_cnt[i] = 0;
     unsigned round_no = 0;
 
     ChainPre pre;
     unsigned pf_v = 0;
     chain_prepare<XCD8>(frames[a.f0], P, 0, w, lane, b, G, pre, err);
-    for (uint32_t f = a.f0; f < a.f1; f++) {
+    for (uint32_t f = a.f0; f < a.f1 && !aborted; f++) {
         SFM_CSTAMP(0);
         if (f > a.f0) {
             // every workgroup arrived after keyframe f-1 (below); its mask stores are out
-#if SFM_REPEAT == 5
-            if (threadIdx.x == 0) {  // diagnostic: a second, empty barrier behind the real one
-                bool okb = chain_wait(a.bar, 2 * (f - a.f0) - 1, G);
-                chain_arrive(a.bar, G, 2 * (f - a.f0));
-                okb = okb && chain_wait(a.bar, 2 * (f - a.f0), G);
-                s_misc[1] = okb ? 1u : 0u;
-            }
-#else
-            if (threadIdx.x == 0) s_misc[1] = chain_wait(a.bar, f - a.f0, G) ? 1u : 0u;
-#endif
+            if (threadIdx.x == 0) s_misc[1] = chain_wait(a.bar, f - a.f0, G, a.timeout_ticks, a.abort_all) ? 1u : 0u;
             __syncthreads();
             if (s_misc[1] == 0u) {  // workgroup-uniform
                 err |= kErrBarrier;
@@ -1159,17 +1094,6 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
             // ---- A: the mask-independent part was prepared ahead for the first pass
             if (i0 || part) chain_prepare<XCD8>(F, P, i0, w, lane, b, G, pre, err);
             uint32_t pos[kChainSegs], mv[kChainSegs];
-#if SFM_REPEAT == 4
-            {  // diagnostic: the mask read and a ballot once more, discarded
-                uint32_t mq[kChainSegs];
-#pragma unroll
-                for (int u = 0; u < kChainSegs; u++) mq[u] = mask_load_coherent(F.mask + (pre.cand[u] ? pre.pixel[u] : 0u));
-                unsigned long long acc = 0;
-#pragma unroll
-                for (int u = 0; u < kChainSegs; u++) acc += __ballot(pre.cand[u] && mq[u] == 0u);
-                if (acc == 0x123456789ull) err |= 16u;
-            }
-#endif
 #pragma unroll
             for (int u = 0; u < kChainSegs; u++) {
                 // only lanes with a candidate pixel ask: a default address would make one mask byte the target
@@ -1191,9 +1115,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
             __syncthreads();
             SFM_CSTAMP(2);
             const uint32_t n = s_misc[0];
-#if SFM_STAMPS
-            if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)(f - a.f0) * gridDim.x + blockIdx.x) * 16 + 7] = n;
-#endif
+            chain_stamp<STAMPS>(a, f, 7, n);
             if (n > (uint32_t)kChainSurv) continue;  // part 0 only: redo in parts (workgroup-uniform)
             // list space for all survivors of this pass: one atomic per workgroup, issued now, its
             // result parked in LDS after step B and used at the end of step C -- nobody waits for it
@@ -1224,17 +1146,14 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                     unsigned int *cnt_next = s_cnt + ((round_no + 1u) & 1u) * (kChainWaves * kWave);
                     round_no++;
                     // ---- B: the (chunk, neighbour) items of this round (:187-216)
-                    for (int rep = 0; rep < (SFM_REPEAT == 1 ? 2 : 1); rep++) {
-                        if (kChainWaves % K == 0)
-                            chain_items<true>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, rep == 0, err);
-                        else
-                            chain_items<false>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, rep == 0, err);
-                    }
+                    if (kChainWaves % K == 0)
+                        chain_items<true>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, err);
+                    else
+                        chain_items<false>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, err);
                     if (threadIdx.x == 0 && c0 == 0) *reinterpret_cast<unsigned long long *>(s_misc + 2) = res_base;
                     __syncthreads();
                     SFM_CSTAMP(3);
                     // ---- C: every wave scatters the masks of its own items (:152-154) ...
-                    for (int rep = 0; rep < (SFM_REPEAT == 3 ? 2 : 1); rep++)
                     for (uint32_t it = w; it < items; it += kChainWaves) {
                         const uint32_t c = it / K, k = it % K;
                         const unsigned pc = cnt_now[c * kWave + lane];
@@ -1245,7 +1164,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                         bool okc = n_obs >= 1;                                               // :218
                         if ((double)n_close < (double)n_obs * P.close_frac) okc = false;     // :229
                         const bool hitk = okc && ((mk >> lane) & 1ull);
-                        if (rep == 0) c_hit += (unsigned)__popcll(__ballot(hitk));
+                        c_hit += (unsigned)__popcll(__ballot(hitk));
                         if (hitk && mp) mask_store_coherent(mp + hp);
                     }
                     cnt_next[w * kWave + lane] = 0;  // all 16 chunk rows of the next round's buffer
@@ -1255,14 +1174,13 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                     if (f + 1 < a.f1 && c0 + R >= chunks && i0 + kChainWaves * kChainSegs >= slots &&
                         (part == 0 || part == (uint32_t)kChainSegs)) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_s_waitcnt(0);  // my mask stores are acknowledged (write-through)
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // my mask stores are acknowledged (write-through)
                         __syncthreads();
-                        if (threadIdx.x == 0) chain_arrive(a.bar, G, CHAIN_EPOCH_ARRIVE(f - a.f0));
+                        if (threadIdx.x == 0) chain_arrive(a.bar, G, f - a.f0 + 1);
                         arrived = true;
                         SFM_CSTAMP(6);
                     }
                     // ... and one wave per chunk forms the fused point and its record
-                    for (int rep = 0; rep < (SFM_REPEAT == 2 ? 2 : 1); rep++)
                     if (fin) {
                         // (the colour, :170, is read by finalize_kernel for the voxels' winners only)
                         const uint32_t pixf = s_spix[min(cf * kWave + lane, (uint32_t)kChainSurv - 1)];
@@ -1342,9 +1260,9 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
         if (f + 1 < a.f1) {
             if (!arrived) {  // a keyframe share without survivors: nothing was scattered
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_s_waitcnt(0);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (threadIdx.x == 0) chain_arrive(a.bar, G, CHAIN_EPOCH_ARRIVE(f - a.f0));
+                if (threadIdx.x == 0) chain_arrive(a.bar, G, f - a.f0 + 1);
                 SFM_CSTAMP(6);
             }
             // while the others arrive: pull the next keyframe's neighbour descriptions into this
@@ -1387,14 +1305,22 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
 __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel(const FrameDev *__restrict__ frames,
                                                                    const FrameDev *__restrict__ nbrpack, ChainArgs a)
 {
-    fuse_chain_body<true>(frames, nbrpack, a);
+    fuse_chain_body<true, false>(frames, nbrpack, a);
 }
 
 __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel_any(const FrameDev *__restrict__ frames,
                                                                        const FrameDev *__restrict__ nbrpack, ChainArgs a)
 {
-    fuse_chain_body<false>(frames, nbrpack, a);
+    fuse_chain_body<false, false>(frames, nbrpack, a);
 }
+
+#if SFM_STAMPS
+__global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel_stamps(const FrameDev *__restrict__ frames,
+                                                                          const FrameDev *__restrict__ nbrpack, ChainArgs a)
+{
+    fuse_chain_body<true, true>(frames, nbrpack, a);
+}
+#endif
 
 // ---- voxel table: first-wins filter for a group of keyframes ------------------------------
 

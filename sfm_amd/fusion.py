@@ -59,7 +59,7 @@ class FusionStats(C.Structure):
         ("table_used", C.c_uint64), ("max_probe", C.c_uint64),
         ("last_run_ms", C.c_double), ("frame_kernels_ms", C.c_double),
         ("fuse_kernel_launches", C.c_uint64), ("fuse_kernel_sum_ms", C.c_double),
-        ("scan_kernel_sum_ms", C.c_double), ("fused_chain", C.c_uint64),
+        ("scan_kernel_sum_ms", C.c_double), ("fused_chain", C.c_uint64), ("chain_fallbacks", C.c_uint64),
     ]
 
     def as_dict(self):

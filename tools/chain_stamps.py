@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: thread-0 phase timestamps of every workgroup of ONE fuse_chain_kernel launch (keyframe
-group SFM_STAMP_GROUP) from the -DSFM_STAMPS=1 build.  Run on the GPU box: python3 tools_chain_stamps.py [group]"""
+group SFM_STAMP_GROUP) from the -DSFM_STAMPS=1 build.  Run on the GPU box: python3 tools/chain_stamps.py [group]"""
 import os, subprocess, sys
 import numpy as np
 group = sys.argv[1] if len(sys.argv) > 1 else "9"

@@ -7,13 +7,13 @@ import subprocess
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
 from sfm_amd import fusion, replay, synth
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n_kf, W, H = 500, 640, 480
 seq = synth.make_sequence(n_kf, W, H, K=(525.0, 525.0, 319.5, 239.5), device=torch.device("cuda", 0), seed=20240315,
                           components=1, radius_m=0.8)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Diagnostic: one rocprofv3 --pmc pass over a short bench run; prints per-kernel counter sums.
-# usage: tools_pmc.sh <tag> <counter> [<counter> ...]   (at most 8 SQ_ counters per pass)
+# usage: tools/pmc.sh <tag> <counter> [<counter> ...]   (at most 8 SQ_ counters per pass)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 1 --warmup 0 --frames 160 --no-cpu-baseline > gpurun_out/pmc_$tag.log 2>&1 || { tail -5 gpurun_out/pmc_$tag.log; exit 1; }

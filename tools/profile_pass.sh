@@ -1,8 +1,8 @@
 #!/bin/bash
 # One rocprofv3 pass over the default bench command on the GPU box (run each pass in its own gpurun call).
-#   tools_profile_pass.sh <tag> kt            kernel trace + stats
-#   tools_profile_pass.sh <tag> fetch|write   one --pmc pass (FETCH_SIZE / WRITE_SIZE), as MI355X_MICROARCH.md prescribes
-# Output: gpurun_out/<tag>_<pass>/ ; then run tools_profile_summary.py <tag> (CPU side is fine).
+#   tools/profile_pass.sh <tag> kt            kernel trace + stats
+#   tools/profile_pass.sh <tag> fetch|write   one --pmc pass (FETCH_SIZE / WRITE_SIZE), as MI355X_MICROARCH.md prescribes
+# Output: gpurun_out/<tag>_<pass>/ ; then run tools/profile_summary.py <tag> (CPU side is fine).
 tag=$1; pass=$2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 case $pass in

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-wave phase timestamps of ONE observe_frame_kernel launch (frame SFM_STAMP_FRAME)
 from the -DSFM_STAMPS=1 build (build/stamps/libsfm_fusion_stamps.so, made by hand:
-hipcc ... -DSFM_STAMPS=1).  Run on the GPU box:  python3 tools_stamps.py [frame]"""
+hipcc ... -DSFM_STAMPS=1).  Run on the GPU box:  python3 tools/stamps.py [frame]"""
 import os, subprocess, sys
 import numpy as np
 frame = sys.argv[1] if len(sys.argv) > 1 else "300"
