@@ -163,6 +163,13 @@ int sfm_fusion_get_frame_counts(sfm_fusion_ctx *ctx, uint64_t *before, uint64_t 
 int sfm_fusion_set_global_order(sfm_fusion_ctx *ctx, const uint32_t *order, uint32_t n);
 /* After sfm_fusion_run: how many local winners each of n_parts owners gets. */
 int sfm_fusion_partition_counts(sfm_fusion_ctx *ctx, uint32_t n_parts, uint64_t *counts);
+/* sfm_fusion_partition_counts for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result; the kernel's per-owner
+ * counters live in a static __device__ array of the library (8 KiB on every GPU the library runs on, held until the
+ * process ends) instead of a buffer the library allocates, and the call performs no hipMalloc / hipFree.  Limit:
+ * n_parts <= 1024 (SFM_E_CAPACITY beyond).  Calls on one GPU share that array: calls that overlap on one GPU (two
+ * ctxs, two threads) race.  Unlike sfm_fusion_partition_counts it does not arm sfm_fusion_export_records. */
+int sfm_fusion_partition_counts_noalloc(sfm_fusion_ctx *ctx, uint32_t n_parts, uint64_t *counts);
 /* Writes the local winners as records, grouped by owner in owner order, into device memory. */
 int sfm_fusion_export_records(sfm_fusion_ctx *ctx, void *dst_dev, uint64_t dst_bytes);
 /* Owner side: first-wins reduce over n received records (device memory); the result replaces

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -33,7 +34,18 @@ hipError_t sort_keys_with_index(void *tmp, size_t &tmp_bytes, const unsigned lon
                                 hipStream_t stream);
 }  // namespace sfm
 
+// Scratch of sfm_fusion_partition_counts_noalloc: the per-owner counters of partition_count_kernel, in the code
+// object itself instead of a hipMalloc'ed buffer.  Every GPU the library runs on holds its own copy (8 KiB) at its own
+// address until the process ends; host code never uses the symbol's name as an address, only the per-device pointer
+// that hipGetSymbolAddress returned (sfm_fusion_create, with that device current).
+constexpr uint32_t kScratchParts = 1024;
+static __device__ __align__(256) unsigned long long scratch[kScratchParts];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU, resolved once per device
 
 struct HostFrame {
     int32_t W = 0, H = 0;
@@ -154,6 +166,8 @@ struct sfm_fusion_ctx {
     DevBuf<double> d_rd_xyz;
     DevBuf<int32_t> d_rd_bgr;
     std::vector<uint64_t> part_counts; // last sfm_fusion_partition_counts result
+    unsigned long long *scratch = nullptr;   // this device's copy of the static scratch array (never freed)
+    unsigned long long *h_part = nullptr;    // pinned, kScratchParts words: read-back of the no-alloc entry point
     uint64_t total_px = 0;
     uint64_t n_out = 0;
     bool have_result = false;
@@ -771,6 +785,19 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
     ok = ok && hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) == hipSuccess;
     for (auto &st : c->stage) ok = ok && hipEventCreateWithFlags(&st.ev, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&c->d_small, kSmallBytes) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_part, kScratchParts * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
+    if (ok && device < kMaxDevices) {
+        // once per device, with that device current (hipSetDevice above): each GPU has its own copy of the array
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (!g_scratch_ptr[device]) {
+            void *p = nullptr;
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) == hipSuccess && p)
+                g_scratch_ptr[device] = p;
+            else
+                (void)hipGetLastError();  // the no-alloc entry point reports SFM_E_UNSUPPORTED on this device
+        }
+        c->scratch = static_cast<unsigned long long *>(g_scratch_ptr[device]);
+    }
     ok = ok && hipHostMalloc(&c->h_small, kSmallBytes, hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) == hipSuccess;
@@ -806,6 +833,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     release(c->d_out_bgr); release(c->d_group_end); release(c->d_cand_end);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->h_part) (void)hipHostFree(c->h_part);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
@@ -1107,6 +1135,32 @@ int sfm_fusion_partition_counts(sfm_fusion_ctx *c, uint32_t n_parts, uint64_t *c
     HIP_TRY(c, hipMemcpyAsync(c->part_counts.data(), c->d_part.p, n_parts * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     std::copy(c->part_counts.begin(), c->part_counts.end(), counts);
+    return SFM_OK;
+}
+
+// The same counts without any allocation: the counters live in this GPU's copy of the static `scratch` array, the
+// read-back goes through a pinned buffer made at sfm_fusion_create.  No hipMalloc / hipFree / std::vector growth on
+// this path.  Calls on one GPU share the array: it is cleared here, and calls that overlap on one GPU race.
+int sfm_fusion_partition_counts_noalloc(sfm_fusion_ctx *c, uint32_t n_parts, uint64_t *counts)
+{
+    if (!c || !counts || n_parts == 0) return fail(c, SFM_E_INVALID, "bad partition argument");
+    if (n_parts > kScratchParts)
+        return fail(c, SFM_E_CAPACITY, "sfm_fusion_partition_counts_noalloc handles at most 1024 parts (static scratch)");
+    if (!c->have_result) return fail(c, SFM_E_INVALID, "no result: call sfm_fusion_run first");
+    if (!c->scratch || !c->h_part) return fail(c, SFM_E_UNSUPPORTED, "no static scratch on this device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    unsigned long long *ptr = c->scratch;  // the device address, never the symbol
+    HIP_TRY(c, hipMemsetAsync(ptr, 0, (size_t)n_parts * sizeof(unsigned long long), s));  // the last call's counts
+    if (c->n_out) {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((c->n_out + 255) / 256, 1024);
+        hipLaunchKernelGGL(partition_count_kernel, dim3(blocks), dim3(256), 0, s, c->d_out_key.p,
+                           (unsigned long long)c->n_out, n_parts, ptr);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_part, ptr, (size_t)n_parts * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (uint32_t p = 0; p < n_parts; p++) counts[p] = c->h_part[p];
     return SFM_OK;
 }
 

@@ -37,6 +37,7 @@ EXPORTS = [
     "sfm_fusion_get_frame_counts", "sfm_fusion_last_error", "sfm_fusion_version",
     "sfm_fusion_set_profiling", "sfm_fusion_set_global_order", "sfm_fusion_partition_counts",
     "sfm_fusion_export_records", "sfm_fusion_merge", "sfm_fusion_set_covisibility",
+    "sfm_fusion_partition_counts_noalloc",
 ]
 SFM_RECORD_BYTES = 48
 
@@ -103,6 +104,7 @@ def load_library():
     L.sfm_fusion_set_profiling.argtypes = [vp, C.c_int]
     L.sfm_fusion_set_global_order.argtypes = [vp, C.POINTER(u32), u32]
     L.sfm_fusion_partition_counts.argtypes = [vp, u32, C.POINTER(u64)]
+    L.sfm_fusion_partition_counts_noalloc.argtypes = [vp, u32, C.POINTER(u64)]
     L.sfm_fusion_export_records.argtypes = [vp, vp, u64]
     L.sfm_fusion_merge.argtypes = [vp, vp, u64]
     L.sfm_fusion_last_error.argtypes = [vp]
@@ -215,6 +217,12 @@ class FusionContext:
         counts = (C.c_uint64 * n_parts)()
         self._check(self._L.sfm_fusion_partition_counts(self._h, n_parts, counts))
         return [int(x) for x in counts]
+
+    def partition_counts_noalloc(self, n_parts: int):
+        """The same counts through the entry point that allocates nothing (static device scratch, <= 1024 parts)."""
+        counts = (C.c_uint64 * max(n_parts, 1))()
+        self._check(self._L.sfm_fusion_partition_counts_noalloc(self._h, n_parts, counts))
+        return [int(x) for x in counts][:n_parts]
 
     def export_records(self, dst_ptr: int, dst_bytes: int):
         self._check(self._L.sfm_fusion_export_records(self._h, C.c_void_p(dst_ptr), dst_bytes))
