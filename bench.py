@@ -7,10 +7,12 @@ order, voxel first-wins filter, compacted cloud left in HBM.  Inputs are synthet
 
 N=1 workload = BASELINE.json configs[1]: 500 keyframes 640x480, TUM-like intrinsics, depth in
 millimetres, 1 cm voxels (voxel_size=10 raw units), T_dist=500 raw units, temporal
-neighbours +-4.  N>1: weak scaling -- every rank fuses its own 500-keyframe trajectory through
-the same room (one covisibility component per rank: components are the unit the
-visibility-mask chain allows to shard), then the per-rank voxel tables are
-exchanged by voxel-key hash partition (RCCL all-to-all) and min-reduced by their owners.
+neighbours +-4.  N>1 = configs[2], STRONG scaling: ONE sequence of 2000 keyframes 1280x720 (one covisibility
+component) cut into N contiguous keyframe blocks, one per rank.  The visibility masks are the only state a
+keyframe hands to later ones: a rank fuses its block starting from the masks its predecessors left and sends the
+masks of the next rank's first keyframes on (point-to-point over RCCL, sfm_amd.dist_fusion.SequenceSplit); then
+the per-rank voxel tables are exchanged by voxel-key hash partition (RCCL all-to-all) and min-reduced by their
+owners.  The union of the owners' clouds is bit-identical to the single-GPU cloud.
 
 Prints ONE JSON line on rank 0.
 """
@@ -61,8 +63,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2_500kf_640x480_1cm", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=0, help="override keyframes per GPU")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2_500kf_640x480_1cm on one GPU, c3_2000kf_1280x720_1cm on several")
+    ap.add_argument("--frames", type=int, default=0, help="override the sequence's keyframe count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=500)
     args = ap.parse_args()
@@ -92,14 +95,19 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from sfm_amd import fusion, synth
+    from sfm_amd import dist_fusion, fusion, synth
 
+    if args.workload is None:
+        args.workload = "c2_500kf_640x480_1cm" if world == 1 else "c3_2000kf_1280x720_1cm"
     n_kf, W, H, K, voxel, t_dist = WORKLOADS[args.workload]
     if args.frames:
         n_kf = args.frames
-    # every rank ray-casts its own trajectory (component id = rank) on its own GPU
-    seq = synth.make_sequence(n_kf, W, H, K=K, device=dev, seed=20240315 + rank,
-                              components=1, radius_m=0.8 * (1.0 + 0.07 * rank))
+    # the sequence's poses and neighbour lists are the same on every rank; a rank renders (ray-casts, on its own
+    # GPU) only the keyframes its ctx holds: its block and the neighbours of the block's keyframes
+    probe = synth.make_sequence(n_kf, W, H, K=K, device="cpu", seed=20240315, components=1, radius_m=0.8, only=(0, 0))
+    plan = dist_fusion.plan_sequence(probe.nbrs, [W * H] * n_kf, world)[rank]
+    lo, hi = (plan.frames[0], plan.frames[-1] + 1) if plan.frames else (0, 0)
+    seq = synth.make_sequence(n_kf, W, H, K=K, device=dev, seed=20240315, components=1, radius_m=0.8, only=(lo, hi))
     torch.cuda.synchronize()
     over = {}
     if os.environ.get("SFM_BENCH_TABLE_CAP"):   # tuning experiments only; the default run sizes automatically
@@ -107,21 +115,43 @@ def main():
     params = fusion.default_params(voxel_size=voxel, T_dist=t_dist, **over)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = fusion.FusionContext(params, local_rank, stream)
-    for i in range(n_kf):
-        ctx.add_keyframe_device(seq.depth[i].data_ptr(), seq.bgr[i].data_ptr(), W, H,
-                                seq.K[i], seq.T_wk[i], seq.T_kw[i])
-    for i in range(n_kf):
-        ctx.set_neighbors(i, seq.nbrs[i])
+    for g in plan.frames:
+        ctx.add_keyframe_device(seq.depth[g - seq.first].data_ptr(), seq.bgr[g - seq.first].data_ptr(), W, H,
+                                seq.K[g], seq.T_wk[g], seq.T_kw[g])
+    for g in range(plan.first, plan.end):
+        ctx.set_neighbors(plan.local[g], [plan.local[j] for j in seq.nbrs[g]])
+    if world > 1:
+        ctx.set_active_range(*plan.active_local)
 
-    merger = None
+    try:
+        return _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, force_exchange, rehearsal)
+    finally:
+        # on every path, before the interpreter's exit handlers run: the ctx's streams and events are
+        # destroyed while the HIP runtime is still alive
+        ctx.close()
+        if world > 1 or force_exchange:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier()
+                dist.destroy_process_group()
+
+
+def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, force_exchange, rehearsal):
     if world > 1 or force_exchange:
-        from sfm_amd import dist_fusion
-        # this rank's keyframes sit at [rank*n_kf, (rank+1)*n_kf) of the global processing order
-        ctx.set_global_order(np.arange(n_kf, dtype=np.uint32) + rank * n_kf)
+        import torch.distributed as dist
+    from sfm_amd import dist_fusion
+    merger = split = None
+    if world > 1 or force_exchange:
+        ctx.set_global_order(np.asarray(plan.frames, dtype=np.uint32))  # tags carry the sequence's keyframe numbers
         merger = dist_fusion.VoxelExchange(ctx, rank, world, dev)
+    if world > 1:
+        split = dist_fusion.SequenceSplit(ctx, plan, lambda g: W * H, rank, world, dev)
 
     def step():
-        ctx.run()
+        if split is not None:
+            split.run()       # masks in from the earlier blocks, this block's keyframe chain, masks out
+        else:
+            ctx.run()
         if merger is not None:
             merger.exchange_and_reduce()
 
@@ -176,7 +206,7 @@ def main():
         except Exception:
             traffic = None
 
-    px_total = n_kf * W * H * world
+    px_total = n_kf * W * H   # the whole sequence, whatever the number of ranks: strong scaling
     value = px_total * args.steps / dt
     out = {
         "metric": "fused depth px/sec (whole node)",
@@ -187,21 +217,22 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if world == 1 else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic (exchange forced at one rank: functional check, not a measurement)" if force_exchange else "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
-        "config": {"workload": args.workload, "keyframes_per_gpu": n_kf, "width": W, "height": H,
+        "config": {"workload": args.workload, "keyframes": n_kf, "keyframes_per_gpu": n_kf / world, "width": W, "height": H,
                    "voxel_size_raw_units": voxel, "T_dist_raw_units": t_dist,
                    "depth_unit": "mm", "neighbours": "temporal +-4",
-                   "sharding": "one covisibility component per GPU" if world > 1 else "single GPU"},
+                   "sharding": "one sequence in contiguous keyframe blocks, masks handed rank to rank, voxel all-to-all"
+                   if world > 1 else "single GPU"},
         "points_per_s": n_points * args.steps / dt,
         "output_points": n_points,
         "device_ms_per_step_rank0": st["last_run_ms"],
         "roofline": {
             "bound": "hbm",
             "kernel": kernel_name,
-            "keyframes_per_launch": n_kf / launches,
+            "keyframes_per_launch": (plan.end - plan.first) / launches,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -228,14 +259,12 @@ def main():
         out["data"] += " (FALLBACK: the kernel pair ran instead of the chain kernel; not the path's figure)"
         print("bench.py: the persistent chain kernel fell back to the kernel pair", file=sys.stderr, flush=True)
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if split is not None:
+        out["mask_handover_bytes_rank0"] = split.bytes_sent // max(1, args.steps + args.warmup)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, min(args.cpu_sample_frames, n_kf), W, H, voxel, t_dist)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    ctx.close()
-    if world > 1 or force_exchange:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 def host_threads():

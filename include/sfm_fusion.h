@@ -176,6 +176,22 @@ int sfm_fusion_export_records(sfm_fusion_ctx *ctx, void *dst_dev, uint64_t dst_b
  * this ctx's cloud (sfm_fusion_num_points / sfm_fusion_read_points). */
 int sfm_fusion_merge(sfm_fusion_ctx *ctx, const void *records_dev, uint64_t n);
 
+/* ---- multi-GPU: ONE covisibility component (one sequence) over several GPUs, by keyframe blocks ----------
+ * No reference counterpart.  The visibility masks (src/dense_reconstruction.cpp:100, :151-154) are the only
+ * state that one keyframe hands to a later one, so the frame loop (:48-52) may be cut anywhere: a ctx fuses the
+ * keyframes [first, end) only, starting from the masks that the blocks before it left, and hands the masks of
+ * later keyframes on.  Every keyframe that a fused keyframe names as a neighbour must be added too (its depth
+ * image and pose are read); keyframes outside the range produce nothing and do not count in n_px.
+ * Call order: add keyframes, neighbours -> set_active_range -> import_masks (0 or more) -> run -> export_masks.
+ * The union of the blocks' clouds after the voxel exchange above is bit-identical to one ctx fusing everything. */
+int sfm_fusion_set_active_range(sfm_fusion_ctx *ctx, uint32_t first, uint32_t end);
+/* ORs masks into the state the next runs start from: keyframes [first, first+count), W*H bytes each, packed back
+ * to back, device memory.  Dropped by set_active_range, add_keyframe, set_neighbors and clear_imported_masks. */
+int sfm_fusion_import_masks(sfm_fusion_ctx *ctx, uint32_t first, uint32_t count, const void *src_dev, uint64_t bytes);
+int sfm_fusion_clear_imported_masks(sfm_fusion_ctx *ctx);
+/* After sfm_fusion_run: the masks of keyframes [first, first+count) as the run left them, same packing. */
+int sfm_fusion_export_masks(sfm_fusion_ctx *ctx, uint32_t first, uint32_t count, void *dst_dev, uint64_t bytes);
+
 const char *sfm_fusion_last_error(sfm_fusion_ctx *ctx);
 const char *sfm_fusion_version(void);
 

@@ -392,20 +392,42 @@ static void *job_run(void *arg)
 }
 
 /* frames are processed in index order.  n_threads splits the pixel loop of one frame over
- * host threads by row blocks, like the reference's par_unseq loop (:95-110). */
+ * host threads by row blocks, like the reference's par_unseq loop (:95-110).
+ *
+ * orc_fuse_ex is the same loop cut at keyframe boundaries, for checking the multi-GPU split of ONE sequence
+ * (no reference counterpart: the reference is one process): only frames [first, end) are processed (:48-52),
+ * the others only lend their images and poses as neighbours and own a visibility mask.  mask_seed[i] (or NULL)
+ * is frame i's mask at the start instead of zeros (:40-45) -- what the ranks before this one left --, and
+ * mask_out[i] (or NULL) receives frame i's mask at the end.  orc_fuse == orc_fuse_ex(0, n_frames, NULL, NULL):
+ * running the blocks one after the other, each seeded with its predecessors' masks, is by construction the
+ * same sequence of process_frame calls on the same mask states. */
+int orc_fuse_ex(const orc_params *P, const orc_frame *frames, uint32_t n_frames, int n_threads,
+                uint32_t first, uint32_t end, const uint8_t *const *mask_seed, uint8_t *const *mask_out,
+                orc_result *out);
+
 int orc_fuse(const orc_params *P, const orc_frame *frames, uint32_t n_frames, int n_threads,
              orc_result *out)
 {
+    return orc_fuse_ex(P, frames, n_frames, n_threads, 0, n_frames, NULL, NULL, out);
+}
+
+int orc_fuse_ex(const orc_params *P, const orc_frame *frames, uint32_t n_frames, int n_threads,
+                uint32_t first, uint32_t end, const uint8_t *const *mask_seed, uint8_t *const *mask_out,
+                orc_result *out)
+{
     memset(out, 0, sizeof(*out));
     if (n_threads < 1) n_threads = 1;
+    if (end > n_frames) end = n_frames;
+    if (first > end) first = end;
     uint8_t **masks = (uint8_t **)calloc(n_frames ? n_frames : 1, sizeof(uint8_t *));
     uint64_t max_px = 0, max_nb = 0;
     for (uint32_t i = 0; i < n_frames; i++) {                        /* :40-45 */
         uint64_t px = (uint64_t)frames[i].W * (uint64_t)frames[i].H;
         masks[i] = (uint8_t *)calloc(px ? px : 1, 1);
+        if (mask_seed && mask_seed[i] && px) memcpy(masks[i], mask_seed[i], px);
         if (px > max_px) max_px = px;
         if (frames[i].n_nbrs > max_nb) max_nb = frames[i].n_nbrs;
-        out->n_px += px;
+        if (i >= first && i < end) out->n_px += px;
         for (uint32_t k = 0; k < frames[i].n_nbrs; k++)
             if (frames[i].nbrs[k] >= n_frames || frames[i].nbrs[k] == i) return -1;
     }
@@ -422,7 +444,7 @@ int orc_fuse(const orc_params *P, const orc_frame *frames, uint32_t n_frames, in
     job *jobs = (job *)calloc((size_t)n_threads, sizeof(job));
     pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
 
-    for (uint32_t fi = 0; fi < n_frames; fi++) {                     /* :48-52 */
+    for (uint32_t fi = first; fi < end; fi++) {                      /* :48-52 */
         const orc_frame *f = &frames[fi];
         uint64_t px = (uint64_t)f->W * (uint64_t)f->H;
         uint32_t n_nb = 0;
@@ -480,7 +502,10 @@ int orc_fuse(const orc_params *P, const orc_frame *frames, uint32_t n_frames, in
         }
         out->tag[i] = r->tag;
     }
-    for (uint32_t i = 0; i < n_frames; i++) free(masks[i]);
+    for (uint32_t i = 0; i < n_frames; i++) {
+        if (mask_out && mask_out[i]) memcpy(mask_out[i], masks[i], (uint64_t)frames[i].W * (uint64_t)frames[i].H);
+        free(masks[i]);
+    }
     free(masks); free(all); free(got); free(local); free(fpts); free(kept); free(gkept);
     free(nb); free(jobs); free(th);
     return 0;

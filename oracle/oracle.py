@@ -104,6 +104,9 @@ def lib():
         L.orc_fuse.argtypes = [C.POINTER(OrcParams), C.POINTER(OrcFrame), C.c_uint32, C.c_int,
                                C.POINTER(OrcResult)]
         L.orc_fuse.restype = C.c_int
+        L.orc_fuse_ex.argtypes = [C.POINTER(OrcParams), C.POINTER(OrcFrame), C.c_uint32, C.c_int, C.c_uint32,
+                                  C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(OrcResult)]
+        L.orc_fuse_ex.restype = C.c_int
         L.orc_free_result.argtypes = [C.POINTER(OrcResult)]
         _lib = L
     return _lib
@@ -177,9 +180,12 @@ def sort_by_key(xyz, bgr, key, tag):
     return xyz[order], bgr[order], key[order], tag[order]
 
 
-def fuse(frames, params=None, n_threads: int = 1) -> Cloud:
+def fuse(frames, params=None, n_threads: int = 1, active=None, mask_seed=None, want_masks=False):
     """frames: list of dicts with depth (H,W) u16, bgr (H,W,3) u8, K (4,), T_wk (4,4),
-    T_kw (4,4), nbrs (list of frame indices, the count-filtered Map::get_neighbors list)."""
+    T_kw (4,4), nbrs (list of frame indices, the count-filtered Map::get_neighbors list).
+
+    active=(first, end), mask_seed={frame: (H,W) u8}, want_masks: the block-wise variant orc_fuse_ex (checks the
+    multi-GPU split of one sequence); with want_masks the result is (Cloud, [mask per frame])."""
     p = params or default_params()
     n = len(frames)
     arr = (OrcFrame * max(n, 1))()
@@ -208,7 +214,21 @@ def fuse(frames, params=None, n_threads: int = 1) -> Cloud:
         a.nbrs = nb.ctypes.data if nb.size else None
         a.n_nbrs = nb.size
     res = OrcResult()
-    rc = lib().orc_fuse(C.byref(p), arr, n, int(n_threads), C.byref(res))
+    first, end = active if active is not None else (0, n)
+    seeds = (C.c_void_p * max(n, 1))()
+    outs = (C.c_void_p * max(n, 1))()
+    masks_out = []
+    for i, f in enumerate(frames):
+        H, W = np.asarray(f["depth"]).shape
+        if mask_seed is not None and i in mask_seed:
+            m = np.ascontiguousarray(mask_seed[i], dtype=np.uint8).reshape(H, W)
+            keep.append(m)
+            seeds[i] = m.ctypes.data if m.size else None
+        if want_masks:
+            m = np.zeros((H, W), dtype=np.uint8)
+            masks_out.append(m)
+            outs[i] = m.ctypes.data if m.size else None
+    rc = lib().orc_fuse_ex(C.byref(p), arr, n, int(n_threads), int(first), int(end), seeds, outs, C.byref(res))
     if rc != 0:
         raise ValueError(f"orc_fuse failed rc={rc} (bad neighbour index?)")
     try:
@@ -220,11 +240,12 @@ def fuse(frames, params=None, n_threads: int = 1) -> Cloud:
         fb = np.ctypeslib.as_array(res.frame_before, shape=(max(n, 1),))[:n].copy()
         fa = np.ctypeslib.as_array(res.frame_after, shape=(max(n, 1),))[:n].copy()
         xyz, bgr, key, tag = sort_by_key(xyz, bgr, key, tag)
-        return Cloud(xyz, bgr, key, tag, fb, fa, int(res.global_before), int(res.global_after),
-                     dict(n_px=int(res.n_px), n_gather=int(res.n_gather), n_acc=int(res.n_acc),
-                          n_hit=int(res.n_hit), n_vox=int(res.n_vox), n_live=int(res.n_live),
-                          n_rej_cov=int(res.n_rej_cov), n_rej_noobs=int(res.n_rej_noobs),
-                          n_rej_far=int(res.n_rej_far)))
+        cloud = Cloud(xyz, bgr, key, tag, fb, fa, int(res.global_before), int(res.global_after),
+                      dict(n_px=int(res.n_px), n_gather=int(res.n_gather), n_acc=int(res.n_acc),
+                           n_hit=int(res.n_hit), n_vox=int(res.n_vox), n_live=int(res.n_live),
+                           n_rej_cov=int(res.n_rej_cov), n_rej_noobs=int(res.n_rej_noobs),
+                           n_rej_far=int(res.n_rej_far)))
+        return (cloud, masks_out) if want_masks else cloud
     finally:
         lib().orc_free_result(C.byref(res))
 

@@ -115,10 +115,14 @@ struct sfm_fusion_ctx {
     // device can hold it), 0 = scan_frame_kernel + observe_frame_kernel per keyframe (SFM_FUSE_CHAIN)
     bool chain = true;
     // Plain launch by default: the grid is one workgroup per CU, each taking (nearly) the whole LDS
-    // of its CU, so it is co-resident whenever the device is not shared; every barrier spin is
-    // bounded, and a timeout sends the ctx to the kernel pair.  SFM_CHAIN_COOP=1 selects
-    // hipLaunchCooperativeKernel instead (about 4 % slower per launch here, and rocprofv3 7.2
-    // crashes in its finalizer after cooperative launches).
+    // of its CU, so it is co-resident whenever the device is not shared (checked against the occupancy
+    // query at create); every barrier spin is bounded, and a timeout sends the run to the kernel pair.
+    // SFM_CHAIN_COOP=1 selects hipLaunchCooperativeKernel instead (about 4 % slower per launch here).
+    // Known, outside this library: a process that made cooperative launches under `rocprofv3 --pmc` ends with
+    // SIGSEGV inside its exit handlers -- libamdhip64's atexit handler -> libhsa-runtime64 shutdown, after the
+    // profiler's "tool finalization", with no frame of this library on the stack and every ctx already
+    // destroyed (tools/exit_probe.py maps the addresses; results are complete before it).  Plain launches
+    // under the same profiler command exit cleanly.
     bool chain_coop = false;
     uint32_t chain_items = 0;        // (chunk, neighbour) LDS slots; 0 = chain kernel unusable here
     size_t chain_lds = 0;
@@ -168,7 +172,14 @@ struct sfm_fusion_ctx {
     std::vector<uint64_t> part_counts; // last sfm_fusion_partition_counts result
     unsigned long long *scratch = nullptr;   // this device's copy of the static scratch array (never freed)
     unsigned long long *h_part = nullptr;    // pinned, kScratchParts words: read-back of the no-alloc entry point
-    uint64_t total_px = 0;
+    uint64_t total_px = 0;             // pixels of the selected keyframes of the active range
+    // One sequence over several GPUs (sfm_fusion_set_active_range): only keyframes [act_first, act_end) are fused
+    // by this ctx, the others lend images and poses and hold masks.  mask_seed = the visibility masks the run
+    // starts from (what the ranks before this one left, sfm_fusion_import_masks) instead of zeros.
+    uint32_t act_first = 0, act_end = 0xFFFFFFFFu;
+    std::vector<uint64_t> mask_off;    // per keyframe: offset of its mask in d_masks
+    DevBuf<uint8_t> d_mask_seed;
+    bool have_seed = false;
     uint64_t n_out = 0;
     bool have_result = false;
     sfm_fusion_stats stats;
@@ -304,14 +315,16 @@ int build_layout(sfm_fusion_ctx *c)
 {
     const size_t n = c->frames.size();
     uint64_t total = 0;
-    std::vector<uint64_t> moff(n);
+    std::vector<uint64_t> &moff = c->mask_off;
+    moff.assign(n, 0);
+    c->have_seed = false;  // offsets may move: imported masks belong to the layout they were imported into
     for (size_t i = 0; i < n; i++) {
         moff[i] = total;
         total += ((uint64_t)c->frames[i].W * c->frames[i].H + 255) / 256 * 256;
     }
     c->total_px = 0;
-    for (auto &f : c->frames)
-        if (f.selected) c->total_px += (uint64_t)f.W * f.H;
+    for (size_t i = c->act_first; i < std::min<size_t>(n, c->act_end); i++)
+        if (c->frames[i].selected) c->total_px += (uint64_t)c->frames[i].W * c->frames[i].H;
     int rc;
     if ((rc = ensure(c, c->d_masks, total))) return rc;
     {
@@ -444,7 +457,9 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     if ((rc = ensure(c, c->d_out_tag, out_cap))) return rc;
     if ((rc = ensure(c, c->d_out_xyz, 3 * out_cap))) return rc;
     if ((rc = ensure(c, c->d_out_bgr, out_cap))) return rc;
-    const size_t n_groups = (n + kGroup - 1) / kGroup;
+    // the keyframes this ctx fuses: all of them, or its block of the sequence (sfm_fusion_set_active_range)
+    const size_t a0 = std::min<size_t>(c->act_first, n), a1 = std::max(a0, std::min<size_t>(c->act_end, n));
+    const size_t n_groups = (a1 - a0 + kGroup - 1) / kGroup;
     while (c->gev.size() < n_groups) {
         hipEvent_t e;
         HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -458,7 +473,10 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
         }
     hipStream_t sa = c->stream, sb = c->stream_b;
     HIP_TRY(c, hipEventRecord(c->ev[0], sa));
-    if (c->d_masks.n) HIP_TRY(c, hipMemsetAsync(c->d_masks.p, 0, c->d_masks.n, sa));  // :40-45
+    if (c->d_masks.n && c->have_seed)  // the masks the earlier blocks of the sequence left
+        HIP_TRY(c, hipMemcpyAsync(c->d_masks.p, c->d_mask_seed.p, c->d_masks.n, hipMemcpyDeviceToDevice, sa));
+    else if (c->d_masks.n)
+        HIP_TRY(c, hipMemsetAsync(c->d_masks.p, 0, c->d_masks.n, sa));  // :40-45
     // the table is first touched by the first group's table kernel: its fill runs on stream B, under the first chain launch
     HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0xFF, table_cap * sizeof(Slot), sb));
     HIP_TRY(c, hipMemsetAsync(c->d_small, 0, kSmallBytes, sa));
@@ -529,7 +547,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             use_chain = false;
     c->chain_ran = use_chain;
     for (size_t g = 0; g < n_groups; g++) {
-        const size_t g0 = g * kGroup, g1 = std::min(n, g0 + kGroup);
+        const size_t g0 = a0 + g * kGroup, g1 = std::min(a1, g0 + kGroup);
         bool group_event_recorded = false;
         if (use_chain) {
             // :48-52 for keyframes [g0, g1) in one launch; order is kept by the in-kernel barrier
@@ -826,6 +844,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
     release(c->d_rd_keys); release(c->d_rd_key3); release(c->d_rd_tag); release(c->d_rd_perm); release(c->d_rd_tmp);
     release(c->d_rd_xyz); release(c->d_rd_bgr);
+    release(c->d_mask_seed);
     release(c->d_part); release(c->d_gorder); release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
     release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_cand); release(c->d_list_xyz); release(c->d_out_xyz);
@@ -1078,14 +1097,15 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     st.scan_kernel_sum_ms = 0;
     st.fused_chain = c->chain_ran ? 1 : 0;
     st.chain_fallbacks = c->chain_fallbacks;
+    const size_t act0 = std::min<size_t>(c->act_first, n), act1 = std::max(act0, std::min<size_t>(c->act_end, n));
     if (c->profile && c->chain_ran) {
-        for (size_t g = 0; g < (n + kGroup - 1) / kGroup; g++) {
+        for (size_t g = 0; g < (act1 - act0 + kGroup - 1) / kGroup; g++) {
             HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * g], c->kev[4 * g + 1]));
             st.fuse_kernel_sum_ms += ms;
             st.fuse_kernel_launches++;
         }
     } else if (c->profile) {
-        for (size_t i = 0; i < n; i++) {
+        for (size_t i = act0; i < act1; i++) {
             if ((uint64_t)c->frames[i].W * c->frames[i].H == 0) continue;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * i], c->kev[4 * i + 1]));
             st.scan_kernel_sum_ms += ms;
@@ -1095,6 +1115,84 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
         }
     }
     c->have_result = true;
+    return SFM_OK;
+}
+
+int sfm_fusion_set_active_range(sfm_fusion_ctx *c, uint32_t first, uint32_t end)
+{
+    if (!c) return SFM_E_INVALID;
+    if (first > end || end > c->frames.size())
+        return fail(c, SFM_E_INVALID, "active range must satisfy first <= end <= number of keyframes added");
+    c->act_first = first;
+    c->act_end = end;
+    c->layout_dirty = true;  // pixel totals (sizing, n_px) follow the range; imported masks are dropped with the layout
+    c->have_result = false;
+    return SFM_OK;
+}
+
+namespace {
+// shared argument check of the mask import/export: frames [first, first+count) packed back to back
+int mask_span(sfm_fusion_ctx *c, uint32_t first, uint32_t count, uint64_t bytes, const void *ptr)
+{
+    if ((uint64_t)first + count > c->frames.size()) return fail(c, SFM_E_INVALID, "mask range names unknown keyframes");
+    uint64_t need = 0;
+    for (uint32_t i = first; i < first + count; i++) need += (uint64_t)c->frames[i].W * c->frames[i].H;
+    if (bytes != need) return fail(c, SFM_E_INVALID, "mask buffer size must be the sum of W*H of the keyframes named");
+    if (need && !ptr) return fail(c, SFM_E_INVALID, "null mask buffer");
+    return SFM_OK;
+}
+}  // namespace
+
+int sfm_fusion_import_masks(sfm_fusion_ctx *c, uint32_t first, uint32_t count, const void *src_dev, uint64_t bytes)
+{
+    if (!c) return SFM_E_INVALID;
+    int rc;
+    if ((rc = mask_span(c, first, count, bytes, src_dev))) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->layout_dirty && (rc = build_layout(c))) return rc;
+    hipStream_t s = c->stream;
+    if (!c->have_seed) {
+        if ((rc = ensure(c, c->d_mask_seed, c->d_masks.n))) return rc;
+        if (c->d_masks.n) HIP_TRY(c, hipMemsetAsync(c->d_mask_seed.p, 0, c->d_masks.n, s));
+        c->have_seed = true;
+    }
+    const uint8_t *src = static_cast<const uint8_t *>(src_dev);
+    for (uint32_t i = first; i < first + count; i++) {
+        const uint64_t px = (uint64_t)c->frames[i].W * c->frames[i].H;
+        if (!px) continue;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((px + 1023) / 1024, 2048);
+        hipLaunchKernelGGL(mask_or_kernel, dim3(blocks), dim3(256), 0, s, c->d_mask_seed.p + c->mask_off[i], src, px);
+        src += px;
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(s));  // the caller's buffer is free again on return
+    c->have_result = false;
+    return SFM_OK;
+}
+
+int sfm_fusion_clear_imported_masks(sfm_fusion_ctx *c)
+{
+    if (!c) return SFM_E_INVALID;
+    c->have_seed = false;
+    c->have_result = false;
+    return SFM_OK;
+}
+
+int sfm_fusion_export_masks(sfm_fusion_ctx *c, uint32_t first, uint32_t count, void *dst_dev, uint64_t bytes)
+{
+    if (!c) return SFM_E_INVALID;
+    if (!c->have_result) return fail(c, SFM_E_INVALID, "no result: call sfm_fusion_run first");
+    int rc;
+    if ((rc = mask_span(c, first, count, bytes, dst_dev))) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint8_t *dst = static_cast<uint8_t *>(dst_dev);
+    for (uint32_t i = first; i < first + count; i++) {
+        const uint64_t px = (uint64_t)c->frames[i].W * c->frames[i].H;
+        if (!px) continue;
+        HIP_TRY(c, hipMemcpyAsync(dst, c->d_masks.p + c->mask_off[i], px, hipMemcpyDeviceToDevice, c->stream));
+        dst += px;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SFM_OK;
 }
 

@@ -1700,6 +1700,16 @@ __global__ __launch_bounds__(256) void merge_finalize_kernel(const Record *rec, 
     }
 }
 
+// ---- one sequence over several GPUs: the visibility masks an earlier block of keyframes left ----------------
+
+// dst[i] |= src[i]: masks are 0 or 255, several earlier blocks may have marked the same keyframe
+__global__ __launch_bounds__(256) void mask_or_kernel(uint8_t *dst, const uint8_t *src, unsigned long long n)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        dst[i] |= src[i];
+}
+
 // ---- read-out: the cloud in voxel-key order, in the layout sfm_fusion_read_points hands out ----
 
 __global__ __launch_bounds__(256) void iota_kernel(uint32_t *idx, unsigned long long n)

@@ -1,5 +1,10 @@
-"""Multi-GPU dense fusion: one process per GPU, keyframes sharded by covisibility component,
-per-GPU voxel tables merged by a voxel-key hash partition + all-to-all + per-owner reduce.
+"""Multi-GPU dense fusion: one process per GPU, per-GPU voxel tables merged by a voxel-key hash partition +
+all-to-all + per-owner reduce.  Two ways to shard the keyframes, both exact:
+
+* by covisibility component (shard_components): components never exchange anything but voxels;
+* ONE component -- one sequence -- by contiguous keyframe blocks (plan_sequence, SequenceSplit): the visibility
+  masks are the only state a keyframe hands to later ones, so a rank fuses its block starting from the masks its
+  predecessors left and hands the masks of later keyframes on (point-to-point, rank to rank, in rank order).
 
 Why components: an accepted pixel masks the pixels it re-observed in its neighbour keyframes
 (reference src/dense_reconstruction.cpp:152-154), so keyframe k depends on every earlier
@@ -55,6 +60,134 @@ def shard_components(nbrs: Sequence[Sequence[int]], weights: Sequence[int], worl
         out[r].extend(comp)
         load[r] += sum(weights[i] for i in comp)
     return [sorted(x) for x in out]
+
+
+def split_blocks(weights: Sequence[int], world: int) -> list:
+    """Cuts keyframes 0..n-1 into `world` contiguous blocks of about equal weight (pixels).  Returns
+    [(first, end)] per rank; a rank may get an empty block when there are fewer keyframes than ranks."""
+    n = len(weights)
+    total = sum(weights)
+    cuts = [0]
+    acc = 0
+    i = 0
+    for r in range(1, world):
+        want = total * r / world
+        while i < n and acc + weights[i] / 2 <= want:
+            acc += weights[i]
+            i += 1
+        cuts.append(i)
+    cuts.append(n)
+    for r in range(1, len(cuts)):
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+class RankPlan:
+    """What one rank does in a sequence split: the block it fuses, the keyframes its ctx holds, and the mask
+    traffic.  All keyframe numbers are global processing-order indices."""
+
+    def __init__(self, first, end, frames, sends, recvs):
+        self.first, self.end = first, end   # active block [first, end)
+        self.frames = frames                # ascending: the block and every neighbour of a keyframe in it
+        self.sends = sends                  # {later rank: [keyframes of ITS block that this block marks]}
+        self.recvs = recvs                  # {earlier rank: [keyframes of this block that IT marks]}
+        self.local = {g: i for i, g in enumerate(frames)}
+
+    @property
+    def active_local(self):
+        """The block as a range of ctx order indices (frames is ascending, the block contiguous in it)."""
+        if self.first == self.end:
+            return (0, 0)
+        return (self.local[self.first], self.local[self.end - 1] + 1)
+
+
+def plan_sequence(nbrs: Sequence[Sequence[int]], weights: Sequence[int], world: int) -> list:
+    """Exact split of one keyframe sequence over `world` ranks by contiguous blocks.  Keyframe i marks pixels in
+    the masks of its LATER neighbours (earlier masks are never read again): rank q therefore sends rank r > q the
+    masks of those keyframes of r's block that a keyframe of q's block names as a neighbour.  Every rank computes
+    the same plan from the same graph."""
+    blocks = split_blocks(weights, world)
+    owner = {}
+    for r, (a, b) in enumerate(blocks):
+        for g in range(a, b):
+            owner[g] = r
+    marks = [dict() for _ in range(world)]  # marks[q][r] = set of keyframes
+    for q, (a, b) in enumerate(blocks):
+        for i in range(a, b):
+            for j in nbrs[i]:
+                if j >= b:
+                    marks[q].setdefault(owner[j], set()).add(j)
+    plans = []
+    for r, (a, b) in enumerate(blocks):
+        frames = set(range(a, b))
+        for i in range(a, b):
+            frames.update(nbrs[i])
+        sends = {t: sorted(v) for t, v in sorted(marks[r].items())}
+        recvs = {q: sorted(marks[q][r]) for q in range(r) if r in marks[q]}
+        plans.append(RankPlan(a, b, sorted(frames), sends, recvs))
+    return plans
+
+
+def _runs(local_ids):
+    """[(first, count)] of consecutive runs in an ascending list of ctx order indices."""
+    out = []
+    for i in local_ids:
+        if out and out[-1][0] + out[-1][1] == i:
+            out[-1][1] += 1
+        else:
+            out.append([i, 1])
+    return [(a, n) for a, n in out]
+
+
+class SequenceSplit:
+    """One pass of the keyframe chain of ONE sequence over all ranks: receive the masks the earlier blocks left,
+    fuse this rank's block, send the masks of later keyframes on.  `ctx` provides clear_imported_masks(),
+    import_masks(first, count, ptr, nbytes), run(), export_masks(first, count, ptr, nbytes) -- sfm_amd.fusion.
+    FusionContext on a GPU, an oracle-backed stand-in in the CPU tests.  `px` maps a global keyframe to W*H."""
+
+    def __init__(self, ctx, plan: RankPlan, px, rank: int, world: int, device, group=None):
+        self.ctx, self.plan, self.px = ctx, plan, px
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.bytes_sent = 0
+        self.bytes_received = 0
+
+    def _staged(self, t):
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"  # gloo moves host memory only
+
+    def run(self):
+        ctx, plan = self.ctx, self.plan
+        ctx.clear_imported_masks()
+        for q, frames in plan.recvs.items():  # ascending ranks: the order the senders finish in
+            n = sum(self.px(g) for g in frames)
+            buf = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
+            if self._staged(buf):
+                h = torch.empty(max(n, 1), dtype=torch.uint8)
+                dist.recv(h, src=q, group=self.group)
+                buf.copy_(h)
+            else:
+                dist.recv(buf, src=q, group=self.group)
+            if buf.is_cuda:
+                torch.cuda.current_stream(buf.device).synchronize()
+            off = 0
+            for first, count in _runs([plan.local[g] for g in frames]):
+                nb = sum(self.px(plan.frames[i]) for i in range(first, first + count))
+                ctx.import_masks(first, count, buf.data_ptr() + off, nb)
+                off += nb
+            self.bytes_received += n
+        ctx.run()
+        for r, frames in plan.sends.items():
+            n = sum(self.px(g) for g in frames)
+            buf = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
+            off = 0
+            for first, count in _runs([plan.local[g] for g in frames]):
+                nb = sum(self.px(plan.frames[i]) for i in range(first, first + count))
+                ctx.export_masks(first, count, buf.data_ptr() + off, nb)
+                off += nb
+            if self._staged(buf):
+                dist.send(buf.cpu(), dst=r, group=self.group)
+            else:
+                dist.send(buf, dst=r, group=self.group)
+            self.bytes_sent += n
 
 
 class VoxelExchange:

@@ -37,7 +37,8 @@ EXPORTS = [
     "sfm_fusion_get_frame_counts", "sfm_fusion_last_error", "sfm_fusion_version",
     "sfm_fusion_set_profiling", "sfm_fusion_set_global_order", "sfm_fusion_partition_counts",
     "sfm_fusion_export_records", "sfm_fusion_merge", "sfm_fusion_set_covisibility",
-    "sfm_fusion_partition_counts_noalloc",
+    "sfm_fusion_partition_counts_noalloc", "sfm_fusion_set_active_range", "sfm_fusion_import_masks",
+    "sfm_fusion_clear_imported_masks", "sfm_fusion_export_masks",
 ]
 SFM_RECORD_BYTES = 48
 
@@ -107,6 +108,10 @@ def load_library():
     L.sfm_fusion_partition_counts_noalloc.argtypes = [vp, u32, C.POINTER(u64)]
     L.sfm_fusion_export_records.argtypes = [vp, vp, u64]
     L.sfm_fusion_merge.argtypes = [vp, vp, u64]
+    L.sfm_fusion_set_active_range.argtypes = [vp, u32, u32]
+    L.sfm_fusion_import_masks.argtypes = [vp, u32, u32, vp, u64]
+    L.sfm_fusion_clear_imported_masks.argtypes = [vp]
+    L.sfm_fusion_export_masks.argtypes = [vp, u32, u32, vp, u64]
     L.sfm_fusion_last_error.argtypes = [vp]
     L.sfm_fusion_last_error.restype = C.c_char_p
     L.sfm_fusion_version.restype = C.c_char_p
@@ -229,6 +234,19 @@ class FusionContext:
 
     def merge(self, records_ptr: int, n: int):
         self._check(self._L.sfm_fusion_merge(self._h, C.c_void_p(records_ptr), n))
+
+    def set_active_range(self, first: int, end: int):
+        """Only keyframes [first, end) are fused by this ctx (one sequence over several GPUs)."""
+        self._check(self._L.sfm_fusion_set_active_range(self._h, int(first), int(end)))
+
+    def import_masks(self, first: int, count: int, src_ptr: int, nbytes: int):
+        self._check(self._L.sfm_fusion_import_masks(self._h, int(first), int(count), C.c_void_p(src_ptr), int(nbytes)))
+
+    def clear_imported_masks(self):
+        self._check(self._L.sfm_fusion_clear_imported_masks(self._h))
+
+    def export_masks(self, first: int, count: int, dst_ptr: int, nbytes: int):
+        self._check(self._L.sfm_fusion_export_masks(self._h, int(first), int(count), C.c_void_p(dst_ptr), int(nbytes)))
 
     def set_profiling(self, enable: bool):
         self._check(self._L.sfm_fusion_set_profiling(self._h, int(bool(enable))))

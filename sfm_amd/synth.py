@@ -29,16 +29,17 @@ class Sequence:
     T_wk: np.ndarray      # (N,4,4) camera->world
     T_kw: np.ndarray      # (N,4,4) world->camera
     nbrs: list            # per frame: ascending list of neighbour frame indices
+    first: int = 0        # make_sequence(only=...): depth[i - first] / bgr[i - first] hold frame i; K, poses, nbrs cover all
 
     @property
     def n_frames(self):
-        return self.depth.shape[0]
+        return len(self.nbrs)
 
     def depth_u16(self, i) -> np.ndarray:
-        return self.depth[i].cpu().numpy().view(np.uint16)
+        return self.depth[i - self.first].cpu().numpy().view(np.uint16)
 
     def bgr_u8(self, i) -> np.ndarray:
-        return self.bgr[i].cpu().numpy()
+        return self.bgr[i - self.first].cpu().numpy()
 
     def frame_dicts(self, lo=0, hi=None):
         """Host-side frame dicts (the oracle's input format)."""
@@ -79,10 +80,12 @@ def _poses(n, unit, rng, yaw_step_deg, radius_m, phase, component):
 
 def make_sequence(n_frames, W, H, K=TUM_K, *, unit=1000.0, seed=20240315, window=4,
                   yaw_step_deg=1.5, radius_m=0.8, holes=0.0, device="cpu", chunk=16,
-                  components=1, room_m=(3.0, 1.5, 3.5)) -> Sequence:
+                  components=1, room_m=(3.0, 1.5, 3.5), only=None) -> Sequence:
     """`components` > 1 lays out that many independent trajectories through the same room,
     one after the other in frame order, with no neighbour edges between them (the unit the
-    multi-GPU path shards by)."""
+    multi-GPU path shards by).  only=(lo, hi): poses and neighbour lists of the whole sequence, images of frames
+    [lo, hi) only -- a rank of a sequence split renders just the keyframes its ctx holds (same pixels as the full
+    sequence would have; needs holes == 0, whose rectangles are drawn frame after frame)."""
     rng = np.random.default_rng(seed)
     dev = torch.device(device)
     fx, fy, cx, cy = K
@@ -112,12 +115,15 @@ def make_sequence(n_frames, W, H, K=TUM_K, *, unit=1000.0, seed=20240315, window
                             ((v - cy) / fy)[:, None].expand(H, W),
                             torch.ones(H, W, dtype=torch.float64, device=dev)], dim=-1)  # (H,W,3)
 
-    depth = torch.empty((n_frames, H, W), dtype=torch.int16, device=dev)
-    bgr = torch.empty((n_frames, H, W, 3), dtype=torch.uint8, device=dev)
+    r_lo, r_hi = (0, n_frames) if only is None else (max(0, only[0]), min(n_frames, only[1]))
+    if only is not None and holes > 0:
+        raise ValueError("only= needs holes == 0")
+    depth = torch.empty((max(r_hi - r_lo, 0), H, W), dtype=torch.int16, device=dev)
+    bgr = torch.empty((max(r_hi - r_lo, 0), H, W, 3), dtype=torch.uint8, device=dev)
     inf = torch.tensor(float("inf"), dtype=torch.float64, device=dev)
     hole_rng = np.random.default_rng(seed + 1)
-    for lo in range(0, n_frames, chunk):
-        hi = min(n_frames, lo + chunk)
+    for lo in range(r_lo, r_hi, chunk):
+        hi = min(r_hi, lo + chunk)
         R = torch.tensor(T_wk[lo:hi, :3, :3], device=dev)           # (n,3,3)
         Cc = torch.tensor(T_wk[lo:hi, :3, 3], device=dev)           # (n,3)
         d = torch.einsum("nij,hwj->nhwi", R, dirs_cam)              # (n,H,W,3)
@@ -150,7 +156,7 @@ def make_sequence(n_frames, W, H, K=TUM_K, *, unit=1000.0, seed=20240315, window
                     x0 = int(hole_rng.integers(0, max(1, W - hw + 1)))
                     y0 = int(hole_rng.integers(0, max(1, H - hh + 1)))
                     zi[k, y0:y0 + hh, x0:x0 + hw] = 0
-        depth[lo:hi] = torch.where(zi >= 32768, zi - 65536, zi).to(torch.int16)
-        bgr[lo:hi] = col
+        depth[lo - r_lo:hi - r_lo] = torch.where(zi >= 32768, zi - 65536, zi).to(torch.int16)
+        bgr[lo - r_lo:hi - r_lo] = col
     Ks = np.tile(np.asarray(K, dtype=np.float64), (n_frames, 1))
-    return Sequence(depth, bgr, Ks, T_wk, T_kw, nbrs)
+    return Sequence(depth, bgr, Ks, T_wk, T_kw, nbrs, r_lo)

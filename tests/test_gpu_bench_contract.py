@@ -1,6 +1,7 @@
 """bench.py's contract on the GPU box: one JSON line with the fields the driver reads, at N=1 on a
-small workload and -- as a functional rehearsal, every rank on GPU 0 over gloo -- through the N>1 path
-(component per rank, exchange by voxel-key hash, owner reduce) as torch.distributed.run launches it."""
+small workload and -- as a functional rehearsal, every rank on GPU 0 over gloo -- through the N>1 path (ONE sequence
+in keyframe blocks, masks handed rank to rank, exchange by voxel-key hash, owner reduce) as torch.distributed.run
+launches it.  The rehearsal's cloud must have exactly as many points as the single-GPU run of the same sequence."""
 import json
 import os
 import subprocess
@@ -52,5 +53,11 @@ def test_two_rank_rehearsal_line(fusion_path):
     j = _last_json(r.stdout)
     for k in NEEDED:
         assert k in j, k
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "REHEARSAL" in j["data"]
-    assert j["output_points"] > 0 and j["value"] > 0
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "REHEARSAL" in j["data"]
+    assert j["output_points"] > 0 and j["value"] > 0 and j["mask_handover_bytes_rank0"] > 0
+    assert j["config"]["keyframes"] == 24 and j["config"]["keyframes_per_gpu"] == 12
+    # the same sequence on one rank: the split must not change the cloud
+    r1 = subprocess.run([sys.executable, "bench.py", "--workload", "tiny_24kf_160x120", "--steps", "1", "--warmup", "0",
+                         "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert _last_json(r1.stdout)["output_points"] == j["output_points"]

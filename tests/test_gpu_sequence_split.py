@@ -1,0 +1,136 @@
+"""ONE keyframe sequence over several ranks, on one GPU: every rank's ctx fuses its block of keyframes starting from
+the masks its predecessors left (sfm_fusion_set_active_range / import_masks / export_masks through the C ABI),
+then the voxel exchange.  The union must be the single-process oracle cloud bit for bit, and the traffic
+counters must add up to the oracle's."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from sfm_amd import dist_fusion, fusion, synth
+from helpers import both_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_split(frames, gp, world, W, H):
+    import torch
+    nbrs = [f["nbrs"] for f in frames]
+    plans = dist_fusion.plan_sequence(nbrs, [W * H] * len(frames), world)
+    ctxs, mail = [], {}
+    for r, plan in enumerate(plans):
+        ctx = fusion.FusionContext(gp)
+        for g in plan.frames:
+            f = frames[g]
+            ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+        for g in range(plan.first, plan.end):
+            ctx.set_neighbors(plan.local[g], [plan.local[j] for j in frames[g]["nbrs"]])
+        ctx.set_global_order(plan.frames)
+        ctx.set_active_range(*plan.active_local)
+        for q, fr in plan.recvs.items():
+            buf = mail[(q, r)]
+            off = 0
+            for first, count in dist_fusion._runs([plan.local[g] for g in fr]):
+                ctx.import_masks(first, count, buf.data_ptr() + off, count * W * H)
+                off += count * W * H
+        ctx.run()
+        for t, fr in plan.sends.items():
+            buf = torch.empty(len(fr) * W * H, dtype=torch.uint8, device="cuda")
+            off = 0
+            for first, count in dist_fusion._runs([plan.local[g] for g in fr]):
+                ctx.export_masks(first, count, buf.data_ptr() + off, count * W * H)
+                off += count * W * H
+            mail[(r, t)] = buf
+        ctxs.append(ctx)
+    return plans, ctxs
+
+
+def _exchange(ctxs, world):
+    import torch
+    counts = [ctx.partition_counts(world) for ctx in ctxs]
+    sends = []
+    for r, ctx in enumerate(ctxs):
+        n = sum(counts[r])
+        buf = torch.empty(max(n, 1) * fusion.SFM_RECORD_BYTES, dtype=torch.uint8, device="cuda")
+        ctx.export_records(buf.data_ptr(), n * fusion.SFM_RECORD_BYTES)
+        sends.append(buf)
+    torch.cuda.synchronize()
+    got = []
+    for owner, ctx in enumerate(ctxs):
+        pieces = []
+        for r in range(world):
+            start = sum(counts[r][:owner]) * fusion.SFM_RECORD_BYTES
+            pieces.append(sends[r][start:start + counts[r][owner] * fusion.SFM_RECORD_BYTES])
+        recv = torch.cat(pieces)
+        torch.cuda.synchronize()
+        ctx.merge(recv.data_ptr(), recv.numel() // fusion.SFM_RECORD_BYTES)
+        got.append(ctx.read_points())
+    xyz = np.concatenate([g[0] for g in got]); bgr = np.concatenate([g[1] for g in got])
+    key = np.concatenate([g[2] for g in got]); tag = np.concatenate([g[3] for g in got])
+    return oracle.sort_by_key(xyz, bgr, key, tag)
+
+
+@pytest.mark.parametrize("world,closure", [(2, False), (3, True), (5, False)])
+def test_block_split_of_one_sequence_equals_single_process(world, closure):
+    W, H = 96, 72
+    seq = synth.make_sequence(41, W, H, K=(78.75, 78.75, 47.5, 35.5), window=3, yaw_step_deg=2.0)
+    frames = seq.frame_dicts()
+    if closure:
+        frames[2]["nbrs"] = sorted(frames[2]["nbrs"] + [40])     # a long-range edge across two blocks
+    assert len(dist_fusion.components([f["nbrs"] for f in frames])) == 1
+    op, gp = both_params(voxel_size=20.0, T_dist=500.0)
+    want = oracle.fuse(frames, op)
+    plans, ctxs = _run_split(frames, gp, world, W, H)
+    stats = [c.stats() for c in ctxs]
+    for k in ("n_px", "n_gather", "n_acc", "n_hit"):
+        assert sum(s[k] for s in stats) == want.counters[k], k
+    fb = np.zeros(len(frames), dtype=np.uint64)
+    fa = np.zeros(len(frames), dtype=np.uint64)
+    for plan, ctx in zip(plans, ctxs):
+        b, a = ctx.frame_counts()
+        a0, a1 = plan.active_local
+        assert b[:a0].sum() == 0 and b[a1:].sum() == 0     # keyframes outside the block produce nothing
+        fb[plan.first:plan.end] = b[a0:a1]
+        fa[plan.first:plan.end] = a[a0:a1]
+    assert np.array_equal(fb, want.frame_before) and np.array_equal(fa, want.frame_after)
+    xyz, bgr, key, tag = _exchange(ctxs, world)
+    assert np.array_equal(key, want.key) and np.array_equal(tag, want.tag)
+    assert np.array_equal(bgr, want.bgr) and np.array_equal(xyz.view(np.uint64), want.xyz.view(np.uint64))
+    for c in ctxs:
+        c.close()
+
+
+def test_active_range_and_mask_calls_check_their_arguments():
+    import torch
+    seq = synth.make_sequence(4, 48, 36, K=(98.4, 98.4, 23.5, 17.5), window=2)
+    frames = seq.frame_dicts()
+    _, gp = both_params(voxel_size=30.0, T_dist=500.0)
+    ctx = fusion.FusionContext(gp)
+    for f in frames:
+        ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+    for i, f in enumerate(frames):
+        ctx.set_neighbors(i, f["nbrs"])
+    buf = torch.zeros(4 * 48 * 36, dtype=torch.uint8, device="cuda")
+    for bad in ((3, 2), (0, 5)):
+        with pytest.raises(fusion.FusionError):
+            ctx.set_active_range(*bad)
+    with pytest.raises(fusion.FusionError):
+        ctx.export_masks(0, 1, buf.data_ptr(), 48 * 36)          # no run yet
+    with pytest.raises(fusion.FusionError):
+        ctx.import_masks(0, 2, buf.data_ptr(), 48 * 36)          # size does not match two keyframes
+    with pytest.raises(fusion.FusionError):
+        ctx.import_masks(3, 2, buf.data_ptr(), 2 * 48 * 36)      # names a fifth keyframe
+    # a fully masked keyframe yields nothing; clearing the import brings its points back
+    ctx.run()
+    n_all = ctx.frame_counts()[0].copy()
+    buf[: 48 * 36] = 255
+    ctx.import_masks(2, 1, buf.data_ptr(), 48 * 36)
+    ctx.run()
+    assert ctx.frame_counts()[0][2] == 0 and n_all[2] > 0
+    ctx.clear_imported_masks()
+    ctx.run()
+    assert np.array_equal(ctx.frame_counts()[0], n_all)
+    # an empty block is a valid rank
+    ctx.set_active_range(2, 2)
+    ctx.run()
+    assert ctx.num_points() == 0 and ctx.stats()["n_px"] == 0
+    ctx.close()
