@@ -78,12 +78,41 @@ def _poses(n, unit, rng, yaw_step_deg, radius_m, phase, component):
     return T_wk, T_kw
 
 
+def _corridor_poses(n, unit, rng, step_m, component):
+    """A long straight walk: the camera moves along +x, `step_m` per keyframe, looking at the side wall (+z) with a
+    slowly swinging yaw and pitch.  Every keyframe sees new wall, so the number of occupied voxels grows linearly
+    with the number of keyframes (BASELINE configs[4]: capacity / collision stress)."""
+    T_wk = np.zeros((n, 4, 4))
+    T_kw = np.zeros((n, 4, 4))
+    jit = rng.normal(0.0, 1.0, size=(n, 4))
+    for i in range(n):
+        yaw = math.radians(12.0) * math.sin(0.013 * i + component) + math.radians(0.2) * jit[i, 0]
+        pitch = math.radians(5.0) * math.sin(0.031 * i) + math.radians(0.2) * jit[i, 1]
+        C = np.array([(i - 0.5 * (n - 1)) * step_m * unit + 0.002 * unit * jit[i, 2],
+                      0.10 * math.sin(0.07 * i) * unit,
+                      0.05 * math.sin(0.011 * i) * unit + 0.002 * unit * jit[i, 3]])
+        fwd = np.array([math.sin(yaw) * math.cos(pitch), math.sin(pitch), math.cos(yaw) * math.cos(pitch)])
+        down0 = np.array([0.0, 1.0, 0.0])
+        right = np.cross(down0, fwd)
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        R = np.stack([right, down, fwd], axis=1)
+        T_wk[i, :3, :3] = R
+        T_wk[i, :3, 3] = C
+        T_wk[i, 3, 3] = 1.0
+        T_kw[i, :3, :3] = R.T
+        T_kw[i, :3, 3] = -R.T @ C
+        T_kw[i, 3, 3] = 1.0
+    return T_wk, T_kw
+
+
 def make_sequence(n_frames, W, H, K=TUM_K, *, unit=1000.0, seed=20240315, window=4,
                   yaw_step_deg=1.5, radius_m=0.8, holes=0.0, device="cpu", chunk=16,
-                  components=1, room_m=(3.0, 1.5, 3.5), only=None) -> Sequence:
+                  components=1, room_m=(3.0, 1.5, 3.5), only=None, corridor_step_m=0.0) -> Sequence:
     """`components` > 1 lays out that many independent trajectories through the same room,
     one after the other in frame order, with no neighbour edges between them (the unit the
-    multi-GPU path shards by).  only=(lo, hi): poses and neighbour lists of the whole sequence, images of frames
+    multi-GPU path shards by).  corridor_step_m > 0: a straight walk along a corridor instead of the
+    circle in the room (_corridor_poses).  only=(lo, hi): poses and neighbour lists of the whole sequence, images of frames
     [lo, hi) only -- a rank of a sequence split renders just the keyframes its ctx holds (same pixels as the full
     sequence would have; needs holes == 0, whose rectangles are drawn frame after frame)."""
     rng = np.random.default_rng(seed)
@@ -92,9 +121,14 @@ def make_sequence(n_frames, W, H, K=TUM_K, *, unit=1000.0, seed=20240315, window
     per = [n_frames // components + (1 if c < n_frames % components else 0) for c in range(components)]
     Ts_wk, Ts_kw, nbrs = [], [], []
     base = 0
+    if corridor_step_m > 0:  # the room becomes a corridor along x that holds the whole walk (pillars: near its middle)
+        room_m = (0.5 * n_frames * corridor_step_m + 3.0, room_m[1], 1.9)
     for c, n_c in enumerate(per):
-        a, b = _poses(n_c, unit, rng, yaw_step_deg, radius_m * (1.0 + 0.07 * c),
-                      phase=2.0 * math.pi * c / max(components, 1) + 0.013 * c, component=c)
+        if corridor_step_m > 0:
+            a, b = _corridor_poses(n_c, unit, rng, corridor_step_m, c)
+        else:
+            a, b = _poses(n_c, unit, rng, yaw_step_deg, radius_m * (1.0 + 0.07 * c),
+                          phase=2.0 * math.pi * c / max(components, 1) + 0.013 * c, component=c)
         Ts_wk.append(a)
         Ts_kw.append(b)
         for i in range(n_c):
