@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: c2_500kf_640x480_1cm on one GPU, c3_2000kf_1280x720_1cm on several")
     ap.add_argument("--frames", type=int, default=0, help="override the sequence's keyframe count")
+    ap.add_argument("--two-phase", action="store_true",
+                    help="one GPU: run every step as verdict_kernel (phase A) + accept_chain_kernel (phase B), the path "
+                         "the waiting ranks of a sequence split take; measures the two terms of the scaling model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=500)
     args = ap.parse_args()
@@ -154,8 +157,10 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
 
     def step():
         if split is not None:
-            split.run()       # masks in from the earlier blocks, this block's keyframe chain, masks out
+            split.run()       # (phase A while waiting,) masks in from the earlier blocks, this block's chain, masks out
         else:
+            if args.two_phase:
+                ctx.precompute()
             ctx.run()
         if merger is not None:
             merger.exchange_and_reduce()
@@ -270,6 +275,10 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
         out["data"] += " (FALLBACK: the kernel pair ran instead of the chain kernel; not the path's figure)"
         print("bench.py: the persistent chain kernel fell back to the kernel pair", file=sys.stderr, flush=True)
 
+    if st["precomputed"]:
+        out["two_phase"] = {"phase_a_ms": st["precompute_ms"], "phase_b_ms": st["frame_kernels_ms"],
+                            "note": "phase A = mask-independent verdicts of every pixel (divides by the number of GPUs); "
+                                    "phase B = the ordered accept/mark/emit chain (does not)"}
     if split is not None:
         out["mask_handover_bytes_rank0"] = split.bytes_sent // max(1, args.steps + args.warmup)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -85,6 +85,8 @@ typedef struct sfm_fusion_stats {
     double fuse_kernel_sum_ms;       /* sum of their durations */
     double scan_kernel_sum_ms;       /* sum of the scan_frame_kernel durations (0 with fuse_chain_kernel) */
     uint64_t fused_chain;            /* 1: the persistent fuse_chain_kernel ran; 0: the scan+observe pair */
+    uint64_t precomputed;            /* 1: the run used the verdicts of sfm_fusion_precompute (two-phase chain) */
+    double precompute_ms;            /* device time of the last sfm_fusion_precompute (phase A) when the run used it */
     uint64_t chain_fallbacks;        /* runs of this ctx that a device-wide barrier timeout (CUs held by someone
                                       * else) sent from fuse_chain_kernel to the kernel pair; the next 8 runs stay
                                       * on the pair, the third fallback is permanent */
@@ -185,6 +187,15 @@ int sfm_fusion_merge(sfm_fusion_ctx *ctx, const void *records_dev, uint64_t n);
  * Call order: add keyframes, neighbours -> set_active_range -> import_masks (0 or more) -> run -> export_masks.
  * The union of the blocks' clouds after the voxel exchange above is bit-identical to one ctx fusing everything. */
 int sfm_fusion_set_active_range(sfm_fusion_ctx *ctx, uint32_t first, uint32_t end);
+/* Optional, for a rank that waits for its predecessors' masks: everything process_pixel computes except its first
+ * test, the visibility mask (:100), is independent of the masks -- the covariance gate (:136-140), geometric_check
+ * (:177-234), the pixels it would mark (:152-154), the fused point (:157-165).  This call computes that for every
+ * pixel of the active keyframes (asynchronously, on the ctx's stream; 34 + 4 * later-neighbours bytes per pixel of
+ * device memory); the sfm_fusion_run calls that follow only read masks, accept, mark and emit, keyframe after
+ * keyframe.  Same cloud, same counts.  It re-observes every pixel, not only those the masks leave (about four
+ * times the arithmetic): worth it only where it overlaps another rank's chain.  The verdicts stay valid until
+ * keyframes, neighbours or the active range change.  SFM_E_UNSUPPORTED where the chain kernel cannot run. */
+int sfm_fusion_precompute(sfm_fusion_ctx *ctx);
 /* ORs masks into the state the next runs start from: keyframes [first, first+count), W*H bytes each, packed back
  * to back, device memory.  Dropped by set_active_range, add_keyframe, set_neighbors and clear_imported_masks. */
 int sfm_fusion_import_masks(sfm_fusion_ctx *ctx, uint32_t first, uint32_t count, const void *src_dev, uint64_t bytes);

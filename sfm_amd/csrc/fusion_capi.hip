@@ -180,6 +180,15 @@ struct sfm_fusion_ctx {
     std::vector<uint64_t> mask_off;    // per keyframe: offset of its mask in d_masks
     DevBuf<uint8_t> d_mask_seed;
     bool have_seed = false;
+    // two-phase chain (sfm_fusion_precompute): the mask-independent verdicts of the active keyframes
+    std::vector<uint32_t> h_nbr;       // filtered neighbours of every keyframe, back to back (FrameDev::nbr_begin)
+    DevBuf<unsigned char> d_verdict_arena;
+    DevBuf<VerdictDev> d_verdicts;
+    bool have_verdicts = false;
+    bool auto_precompute = false;      // SFM_PRECOMPUTE=1: every run goes through the two phases (tests)
+    bool verdicts_ran = false;
+    hipEvent_t ev_pa[2] = {nullptr, nullptr};  // around phase A's launches
+    bool pa_timed = false;
     uint64_t n_out = 0;
     bool have_result = false;
     sfm_fusion_stats stats;
@@ -342,7 +351,9 @@ int build_layout(sfm_fusion_ctx *c)
     }
     std::vector<FrameDev> &fd = c->h_frames;
     fd.assign(n, FrameDev());
-    std::vector<uint32_t> nbr;
+    c->have_verdicts = false;
+    std::vector<uint32_t> &nbr = c->h_nbr;
+    nbr.clear();
     // lookup tables, one per distinct (f, c, extent) / focal length
     struct Axis { double f, c; int n; size_t off; };
     std::vector<Axis> axes;
@@ -546,6 +557,8 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
         if (!chain_div_ok(a.P, c->frames[i].K, c->frames[i].W, c->frames[i].H, c->h_frames[i].Twk, c->h_frames[i].Tkw))
             use_chain = false;
     c->chain_ran = use_chain;
+    const bool use_verdicts = use_chain && c->have_verdicts;
+    c->verdicts_ran = use_verdicts;
     for (size_t g = 0; g < n_groups; g++) {
         const size_t g0 = a0 + g * kGroup, g1 = std::min(a1, g0 + kGroup);
         bool group_event_recorded = false;
@@ -582,7 +595,22 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             (void)stamp_this;
 #endif
             if (c->profile) HIP_TRY(c, hipEventRecord(c->kev[4 * g], sa));
-            if (c->chain_coop) {
+            if (use_verdicts) {
+                // phase B of the two-phase chain: accept / scatter / emit from the stored verdicts
+                AcceptArgs aa;
+                aa.c = ca;
+                const VerdictDev *vd = c->d_verdicts.p;
+                aa.v_first = (uint32_t)a0;
+                aa.pad = 0;
+                hipEvent_t stop = c->profile ? nullptr : c->gev[g];
+#if SFM_STAMPS
+                if (stamp_this)
+                    hipExtLaunchKernelGGL(accept_chain_kernel_stamps, dim3(c->n_cu), dim3(kChainThreads), 0, sa, nullptr, stop, 0, fr, vd, aa);
+                else
+#endif
+                hipExtLaunchKernelGGL(accept_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), 0, sa, nullptr, stop, 0, fr, vd, aa);
+                group_event_recorded = !c->profile;
+            } else if (c->chain_coop) {
                 void *args[] = {(void *)&fr, (void *)&np, (void *)&ca};
                 const void *kern = c->chain_xcd ? (const void *)fuse_chain_kernel : (const void *)fuse_chain_kernel_any;
                 if (hipLaunchCooperativeKernel(kern, dim3(c->n_cu), dim3(kChainThreads), args,
@@ -784,6 +812,7 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
     if (const char *e = std::getenv("SFM_CHAIN_XCD")) c->chain_xcd = c->chain_xcd && std::atoi(e) != 0;
     if (const char *e = std::getenv("SFM_FUSE_CHAIN")) c->chain = std::atoi(e) != 0;
     if (const char *e = std::getenv("SFM_CHAIN_COOP")) c->chain_coop = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SFM_PRECOMPUTE")) c->auto_precompute = std::atoi(e) != 0;
     if (const char *e = std::getenv("SFM_TABLE_THREADS")) {
         const int v = std::atoi(e);
         if (v == 64 || v == 128 || v == 256) c->table_threads = (uint32_t)v;
@@ -818,6 +847,7 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
     }
     ok = ok && hipHostMalloc(&c->h_small, kSmallBytes, hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    for (int i = 0; ok && i < 2; i++) ok = hipEventCreate(&c->ev_pa[i]) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_b_done, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -844,7 +874,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
     release(c->d_rd_keys); release(c->d_rd_key3); release(c->d_rd_tag); release(c->d_rd_perm); release(c->d_rd_tmp);
     release(c->d_rd_xyz); release(c->d_rd_bgr);
-    release(c->d_mask_seed);
+    release(c->d_mask_seed); release(c->d_verdict_arena); release(c->d_verdicts);
     release(c->d_part); release(c->d_gorder); release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
     release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_cand); release(c->d_list_xyz); release(c->d_out_xyz);
@@ -854,6 +884,8 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->h_part) (void)hipHostFree(c->h_part);
     for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_pa)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_b_done) (void)hipEventDestroy(c->ev_b_done);
@@ -1005,6 +1037,7 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     }
     if (c->layout_dirty && (rc = build_layout(c))) return rc;
     c->have_result = false;
+    if (c->auto_precompute && !c->have_verdicts && c->chain && (rc = sfm_fusion_precompute(c)) && rc != SFM_E_UNSUPPORTED) return rc;
     c->part_counts.clear();  // sfm_fusion_export_records needs counts of THIS run's cloud
     // a fallback is not for life: after kChainRetryRuns runs on the kernel pair the chain kernel is tried again
     // (three fallbacks in a ctx's life make it permanent: something else owns CUs of this device for good)
@@ -1097,6 +1130,12 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     st.scan_kernel_sum_ms = 0;
     st.fused_chain = c->chain_ran ? 1 : 0;
     st.chain_fallbacks = c->chain_fallbacks;
+    st.precomputed = c->verdicts_ran ? 1 : 0;
+    st.precompute_ms = 0;
+    if (c->verdicts_ran && c->pa_timed) {  // the events completed before this run's kernels on the same stream
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pa[0], c->ev_pa[1]));
+        st.precompute_ms = ms;
+    }
     const size_t act0 = std::min<size_t>(c->act_first, n), act1 = std::max(act0, std::min<size_t>(c->act_end, n));
     if (c->profile && c->chain_ran) {
         for (size_t g = 0; g < (act1 - act0 + kGroup - 1) / kGroup; g++) {
@@ -1115,6 +1154,87 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
         }
     }
     c->have_result = true;
+    return SFM_OK;
+}
+
+int sfm_fusion_precompute(sfm_fusion_ctx *c)
+{
+    if (!c) return SFM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if (c->up_pending) {
+        HIP_TRY(c, hipEventRecord(c->ev_up, c->stream_up));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up, 0));
+        c->up_pending = false;
+    }
+    if (c->layout_dirty && (rc = build_layout(c))) return rc;
+    c->have_verdicts = false;
+    const size_t n = c->frames.size();
+    for (size_t i = 0; i < n; i++)
+        for (uint32_t j : c->frames[i].nbrs)
+            if (j >= n || j == i) return fail(c, SFM_E_INVALID, "neighbour index out of range");
+    if (!c->chain || c->chain_items == 0)
+        return fail(c, SFM_E_UNSUPPORTED, "the two-phase chain needs the device-wide barrier this device or ctx does not have");
+    const size_t a0 = std::min<size_t>(c->act_first, n), a1 = std::max(a0, std::min<size_t>(c->act_end, n));
+    DevParams P;
+    P.base_line = c->prm.base_line; P.T_cov = c->prm.T_cov; P.voxel_size = c->prm.voxel_size;
+    P.tau_dist2 = sqrt_threshold(c->prm.T_dist); P.S0 = c->prm.S[0]; P.S1 = c->prm.S[1]; P.S2 = c->prm.S[2];
+    P.depth_div = c->prm.depth_div; P.close_frac = c->prm.close_frac;
+    // the shared-reciprocal divisions need operands in their range, for the keyframe and for its neighbours
+    bool shared = true;
+    for (size_t i = 0; shared && i < n; i++)
+        shared = chain_div_ok(P, c->frames[i].K, c->frames[i].W, c->frames[i].H, c->h_frames[i].Twk, c->h_frames[i].Tkw);
+    // arena: per active keyframe info u16[P] | rec 32 B [P] | hits u32 [n_later][P], each 256-byte aligned
+    auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
+    std::vector<VerdictDev> hv(a1 - a0);
+    std::vector<uint64_t> off(a1 - a0);
+    uint64_t total = 0;
+    for (size_t i = a0; i < a1; i++) {
+        const FrameDev &F = c->h_frames[i];
+        VerdictDev &V = hv[i - a0];
+        std::memset(&V, 0, sizeof V);
+        for (uint32_t k = 0; k < F.nbr_count; k++) {
+            const uint32_t j = c->h_nbr[F.nbr_begin + k];
+            if (j > i) V.later_mask[V.n_later++] = c->h_frames[j].mask;
+        }
+        const uint64_t px = (uint64_t)F.W * F.H;
+        off[i - a0] = total;
+        total += up(px * 2) + up(px * sizeof(VerdictRec)) + up(px * 4 * V.n_later);
+    }
+    if ((rc = ensure(c, c->d_verdict_arena, total))) return rc;
+    if ((rc = ensure(c, c->d_verdicts, hv.size()))) return rc;
+    for (size_t i = a0; i < a1; i++) {
+        const FrameDev &F = c->h_frames[i];
+        VerdictDev &V = hv[i - a0];
+        const uint64_t px = (uint64_t)F.W * F.H;
+        unsigned char *p = c->d_verdict_arena.p + off[i - a0];
+        V.info = reinterpret_cast<uint16_t *>(p);
+        V.rec = reinterpret_cast<VerdictRec *>(p + up(px * 2));
+        V.hits = reinterpret_cast<uint32_t *>(p + up(px * 2) + up(px * sizeof(VerdictRec)));
+    }
+    if (!hv.empty())
+        HIP_TRY(c, hipMemcpy(c->d_verdicts.p, hv.data(), hv.size() * sizeof(VerdictDev), hipMemcpyHostToDevice));
+    // phase A: no order between keyframes; one launch per 32 keyframes keeps the grids moderate
+    HIP_TRY(c, hipEventRecord(c->ev_pa[0], c->stream));
+    for (size_t g0 = a0; g0 < a1; g0 += kGroup) {
+        const size_t g1 = std::min(a1, g0 + kGroup);
+        uint64_t max_px = 0;
+        for (size_t i = g0; i < g1; i++) max_px = std::max<uint64_t>(max_px, (uint64_t)c->frames[i].W * c->frames[i].H);
+        if (!max_px) continue;
+        const dim3 grid((uint32_t)((max_px + 255) / 256), (uint32_t)(g1 - g0));
+        if (shared)
+            hipLaunchKernelGGL(verdict_kernel<true>, grid, dim3(256), 0, c->stream, (const FrameDev *)c->d_frames.p,
+                               (const FrameDev *)c->d_nbrpack.p, (const VerdictDev *)c->d_verdicts.p, (uint32_t)g0,
+                               (uint32_t)(g0 - a0), P, dev_stat(c));
+        else
+            hipLaunchKernelGGL(verdict_kernel<false>, grid, dim3(256), 0, c->stream, (const FrameDev *)c->d_frames.p,
+                               (const FrameDev *)c->d_nbrpack.p, (const VerdictDev *)c->d_verdicts.p, (uint32_t)g0,
+                               (uint32_t)(g0 - a0), P, dev_stat(c));
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_pa[1], c->stream));
+    c->pa_timed = true;
+    c->have_verdicts = true;  // stream-ordered: sfm_fusion_run's launches follow on the same stream
     return SFM_OK;
 }
 

@@ -488,11 +488,16 @@ __device__ __forceinline__ ObsProj obs_project(const FrameDev &L, double pwx, do
 
 // dense_reconstruction.cpp:193-216 after the gathers: back-projection of the neighbour's depth,
 // its covariance trace (bit-equal to cov_trace_tab), the kept (:204) / close (:224) tests, and the
-// weighted observation (:161-162) left in LDS for the fusing wave.
+// weighted observation (:161-162): q*(1/w) and 1/w (valid where kept).
+struct ObsVal {
+    double wx, wy, wz, inv;
+    bool kept, close;
+};
+
 template <bool SHARED>
-__device__ __forceinline__ void obs_finish(const FrameDev &L, const DevParams &P, const ObsProj &p, uint32_t draw,
-                                           double x, double y, double2 e01, double2 e23, double pwx, double pwy,
-                                           double pwz, double *o, uint32_t *hit, bool &kept, bool &close, bool &bad)
+__device__ __forceinline__ ObsVal obs_values(const FrameDev &L, const DevParams &P, const ObsProj &p, uint32_t draw,
+                                             double x, double y, double2 e01, double2 e23, double pwx, double pwy,
+                                             double pwz, bool &bad)
 {
     const double d = (double)draw;
     const double qcx = x * d, qcy = y * d, qcz = d;
@@ -500,16 +505,32 @@ __device__ __forceinline__ void obs_finish(const FrameDev &L, const DevParams &P
     const double qy = row_apply(L.Twk, 1, qcx, qcy, qcz);
     const double qz = row_apply(L.Twk, 2, qcx, qcy, qcz);
     const double wgt = cov_trace_vals<SHARED>(P, p.ix, p.iy, e01, e23, bad);  // :202
-    kept = p.vis && (wgt < P.T_cov);                                     // :204
+    ObsVal r;
+    r.kept = p.vis && (wgt < P.T_cov);                                   // :204
     const double dx = qx - pwx, dy = qy - pwy, dz = qz - pwz;
     const double s = (dx * dx + dy * dy) + dz * dz;                      // norm(): (e0+e1)+e2
-    close = kept && (s < P.tau_dist2);                                   // :224
+    r.close = r.kept && (s < P.tau_dist2);                               // :224
+    r.inv = 1.0 / wgt;                                                   // :161-162
+    r.wx = qx * r.inv;
+    r.wy = qy * r.inv;
+    r.wz = qz * r.inv;
+    return r;
+}
+
+// ... left in LDS for the fusing wave (the chain kernels)
+template <bool SHARED>
+__device__ __forceinline__ void obs_finish(const FrameDev &L, const DevParams &P, const ObsProj &p, uint32_t draw,
+                                           double x, double y, double2 e01, double2 e23, double pwx, double pwy,
+                                           double pwz, double *o, uint32_t *hit, bool &kept, bool &close, bool &bad)
+{
+    const ObsVal r = obs_values<SHARED>(L, P, p, draw, x, y, e01, e23, pwx, pwy, pwz, bad);
+    kept = r.kept;
+    close = r.close;
     if (kept) {
-        const double inv = 1.0 / wgt;                                    // :161-162
-        o[0] = qx * inv;
-        o[64] = qy * inv;
-        o[128] = qz * inv;
-        o[192] = inv;
+        o[0] = r.wx;
+        o[64] = r.wy;
+        o[128] = r.wz;
+        o[192] = r.inv;
         *hit = p.npix;
     }
 }
@@ -1319,6 +1340,351 @@ __global__ __launch_bounds__(kChainThreads) void fuse_chain_kernel_stamps(const 
                                                                           const FrameDev *__restrict__ nbrpack, ChainArgs a)
 {
     fuse_chain_body<true, true>(frames, nbrpack, a);
+}
+#endif
+
+// ---- the keyframe chain in two phases (one sequence over several GPUs) -------------------------------------
+//
+// Everything process_pixel computes except its first test, `mask == 0` (:100), is independent of the visibility
+// masks: the covariance gate, the re-observations in the neighbours, the geometric verdict (:218-231), the pixels
+// it would mark (:152-154) and the fused point (:157-165).  So the work splits exactly:
+//   verdict_kernel        (phase A) for EVERY gate-passing pixel of a keyframe, whatever its mask: verdict, hit
+//                         pixels in the later neighbours, fused point and key.  No ordering between keyframes:
+//                         a throughput kernel that a rank runs on its block while the ranks before it still chain.
+//   accept_chain_kernel   (phase B) the chain proper, keyframe after keyframe behind the same device-wide barrier
+//                         as fuse_chain_kernel: read mask and verdict, accept, scatter the stored hits, emit the
+//                         record.  A few memory round trips per keyframe, no arithmetic.
+// Phase A does the re-observations of every pixel, about four times what fuse_chain_kernel does for the pixels the
+// masks leave: on one GPU the fused kernel is faster.  With N GPUs phase A divides by N and phase B does not.
+
+struct VerdictRec {  // 32 bytes per pixel, valid where the verdict is positive
+    unsigned long long key;  // packed voxel key of the fused point
+    double x, y, z;          // the fused point (:164), x86 NaN bits included
+};
+
+constexpr uint16_t kVOk = 0x8000u;        // geometric_check passed: the pixel yields a point if its mask is clear
+constexpr uint16_t kVKeyRange = 0x4000u;  // ... but its voxel index does not fit the packed key
+constexpr uint16_t kVCand = 0x2000u;      // depth > 0 and the covariance gate passed: the pixel reaches geometric_check
+// info = flags | kept observations << 6 | visible projections  (6 bits each: at most kMaxK = 32)
+
+struct VerdictDev {  // one per keyframe of the active range
+    uint16_t *info;        // [W*H]
+    VerdictRec *rec;       // [W*H]
+    uint32_t *hits;        // [n_later][W*H] pixel marked in the s-th LATER neighbour, kNoHit where nothing is kept
+    uint32_t n_later, pad;
+    uint8_t *later_mask[kMaxK];  // masks of the later neighbours, in neighbour order
+};
+
+template <bool SHARED>
+__global__ __launch_bounds__(256) void verdict_kernel(const FrameDev *__restrict__ frames,
+                                                      const FrameDev *__restrict__ nbrpack,
+                                                      const VerdictDev *__restrict__ verdicts, uint32_t f0, uint32_t v0,
+                                                      DevParams P, StatShard *stat)
+{
+    const uint32_t f = f0 + blockIdx.y;
+    const FrameDev &F = frames[f];
+    const VerdictDev &V = verdicts[v0 + blockIdx.y];
+    const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
+    const uint32_t pix = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x * 256u >= npx) return;  // the grid is sized for the launch's largest keyframe
+    const bool in = pix < npx;
+    const uint32_t K = F.nbr_count;
+    const FrameDev *nbp = nbrpack + F.nbr_begin;
+    bool bad = false;
+    // validity (:101), covariance gate (:136-140), back-projection (:143-144): chain_prepare's arithmetic
+    const uint32_t dv = ldg(F.depth + (in ? pix : 0u));
+    bool cand = in && dv > 0u && K > 0u;
+    const int u = cand ? (int)(pix % (uint32_t)F.W) : 0, v = cand ? (int)(pix / (uint32_t)F.W) : 0;
+    const double *e = F.ctab + 4 * (size_t)(cand ? dv : 1u);
+    const double2 e01 = ldg2(e), e23 = ldg2(e + 2);
+    const double xn = ldg(F.xtab + u), yn = ldg(F.ytab + v);
+    {
+        bool bd = false;
+        const double tr = cov_trace_vals<SHARED>(P, u, v, e01, e23, bd);
+        bad = bad || (bd && cand);
+        cand = cand && !(tr > P.T_cov);
+    }
+    const double dsrc = (double)dv;
+    const double pcx = xn * dsrc, pcy = yn * dsrc, pcz = dsrc;
+    const double pwx = row_apply(F.Twk, 0, pcx, pcy, pcz);
+    const double pwy = row_apply(F.Twk, 1, pcx, pcy, pcz);
+    const double pwz = row_apply(F.Twk, 2, pcx, pcy, pcz);
+    // geometric_check (:187-216) over the neighbours in order; the sums of :157-165 run along
+    double wx = 0, wy = 0, wz = 0, total = 0;
+    unsigned n_obs = 0, n_close = 0, n_vis = 0, slot = 0;
+    if (__ballot(cand) != 0ull) {
+        for (uint32_t k = 0; k < K; k++) {
+            const FrameDev &L = nbp[k];
+            bool bd = false;
+            const ObsProj p = obs_project<SHARED>(L, pwx, pwy, pwz, cand, bd);
+            const uint32_t draw = ldg(L.depth + p.npix);                 // :193 (no d>0 test)
+            const double x = ldg(L.xtab + p.ix), y = ldg(L.ytab + p.iy);
+            const double *en = L.ctab + 4 * (size_t)draw;
+            const double2 n01 = ldg2(en), n23 = ldg2(en + 2);
+            const ObsVal o = obs_values<SHARED>(L, P, p, draw, x, y, n01, n23, pwx, pwy, pwz, bd);
+            bad = bad || (bd && p.vis);
+            n_vis += p.vis ? 1u : 0u;
+            n_obs += o.kept ? 1u : 0u;
+            n_close += o.close ? 1u : 0u;
+            wx = o.kept ? wx + o.wx : wx;
+            wy = o.kept ? wy + o.wy : wy;
+            wz = o.kept ? wz + o.wz : wz;
+            total = o.kept ? total + o.inv : total;
+            if (L.order > F.order) {  // wave-uniform: masks of earlier keyframes are never read again
+                if (cand) V.hits[(size_t)slot * npx + pix] = o.kept ? p.npix : kNoHit;  // read for accepted pixels only
+                slot++;
+            }
+        }
+    }
+    bool ok = cand && n_obs >= 1;                                        // :218
+    if ((double)n_close < (double)n_obs * P.close_frac) ok = false;      // :229
+    uint16_t info = cand ? (uint16_t)(kVCand | (n_obs << 6) | n_vis) : (uint16_t)0;
+    if (ok) {
+        const double fx = x86_nan(wx / total), fy = x86_nan(wy / total), fz = x86_nan(wz / total);  // :164
+        unsigned long long c0_, c1_, c2_;
+        const int fits = (int)axis_code_of(fx, P.voxel_size, c0_) & (int)axis_code_of(fy, P.voxel_size, c1_) &
+                         (int)axis_code_of(fz, P.voxel_size, c2_);
+        info |= fits ? kVOk : (uint16_t)(kVOk | kVKeyRange);
+        VerdictRec r;
+        r.key = (c0_ << 42) | (c1_ << 21) | c2_;
+        r.x = fx; r.y = fy; r.z = fz;
+        V.rec[pix] = r;
+    }
+    if (in) V.info[pix] = info;
+    if (__ballot(bad) != 0ull && lane_id() == 0) atomicOr(&stat[blockIdx.x % kStatShards].err, kErrDivRange);
+}
+
+// accept_chain_kernel: keyframes [f0, f1) of one launch, one 1024-thread workgroup per CU, the barrier, abort and
+// list-boundary machinery of fuse_chain_kernel.  A keyframe is dealt in runs of 64 pixels (one wave, coalesced):
+// run t goes to workgroup t mod G, so that every workgroup samples the whole image -- accepted pixels cluster where
+// the camera sees something new, and the marks of a 1024-pixel tile full of them (4096 one-byte write-through
+// stores from one CU) made the keyframe wait for that one workgroup.  A workgroup takes 64 runs per pass (kAccIter
+// per wave; one list reservation per workgroup and pass).
+constexpr int kAccIter = 4;
+
+struct AcceptArgs {
+    ChainArgs c;                 // f0, f1, group, list, stat, bar, P, abort_all, timeout_ticks (item_cap, stamps unused)
+    uint32_t v_first, pad;       // the kernel's `verdicts` argument holds keyframe f at [f - v_first]
+};
+
+// frames and verdicts are never written by any kernel while this one runs: as __restrict__ const kernel arguments
+// their fields arrive through the scalar cache into SGPRs (passed inside the argument struct, the verdict pointers
+// were re-read by vector loads with a full vmcnt(0) wait in front of every prefetch load: 6 us per keyframe)
+template <bool STAMPS>
+__device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ frames,
+                                                  const VerdictDev *__restrict__ verdicts, const AcceptArgs &aa)
+{
+    static_assert(kAccIter * kChainWaves == kWave, "one wave scans the pass's per-wave counts");
+    __shared__ unsigned int s_wave[kAccIter * kChainWaves], s_off[kAccIter * kChainWaves];
+    __shared__ unsigned int s_go;
+    __shared__ unsigned long long s_base;
+    const ChainArgs &a = aa.c;
+    const unsigned lane = lane_id();
+    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned b = blockIdx.x, G = gridDim.x;
+    unsigned c_gather = 0, c_hit = 0, err = 0;
+    const bool aborted = bar_load(a.abort_all) != 0u;
+    if (aborted) err |= kErrBarrier;
+    for (uint32_t f = a.f0; f < a.f1 && !aborted; f++) {
+        const FrameDev &F = frames[f];
+        const VerdictDev &V = verdicts[f - aa.v_first];
+        const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
+        SFM_CSTAMP(0);
+        const uint32_t runs = F.nbr_count ? (npx + kWave - 1) / kWave : 0u;            // 64-pixel runs of the keyframe
+        const uint32_t mine = (runs + G * kChainWaves - 1) / (G * kChainWaves);         // runs per wave (same for every workgroup)
+        // Neither the verdicts nor the pixels they would mark depend on the masks: the first pass's verdicts and its
+        // stored hit pixels in the first four later neighbours are requested before the barrier opens (dense,
+        // coalesced loads for every pixel of the tile, accepted or not: four times the bytes, none of the latency)
+        // (the loads are unconditional -- a lane without a pixel reads pixel 0, a missing neighbour slot the last
+        // one -- and nothing looks at their values before the barrier: no wait is placed in front of it)
+        // (loads return in order within a wave: thread 0 looks at the barrier flag once BEFORE the prefetch and waits
+        // for that value alone (0.2 us), so that a barrier that is already open -- the last workgroup to arrive, which
+        // every other one waits for -- does not cost the latency of twenty cold loads in front of the first poll)
+        bool open_early = false;
+        if (f > a.f0 && threadIdx.x == 0) {
+            const unsigned early = chain_progress(a.bar, G);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            open_early = early >= f - a.f0;
+        }
+        uint32_t pixv[kAccIter], infov[kAccIter], h[kAccIter][4];
+        bool inv[kAccIter];
+        const uint32_t nl = V.n_later;
+        const uint32_t ql = nl ? nl - 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < kAccIter; j++) {
+            pixv[j] = (((uint32_t)j * kChainWaves + w) * G + b) * kWave + lane;
+            inv[j] = (uint32_t)j < mine && pixv[j] < npx;
+            const uint32_t pa = inv[j] ? pixv[j] : 0u;
+            infov[j] = mine ? (uint32_t)ldg(V.info + pa) : 0u;  // (uniform conditions: an empty keyframe has nothing to read)
+#pragma unroll
+            for (int q = 0; q < 4; q++) h[j][q] = (mine && nl) ? ldg(V.hits + (size_t)min((uint32_t)q, ql) * npx + pa) : kNoHit;
+        }
+        chain_stamp<STAMPS>(a, f, 10);
+        if (f > a.f0) {
+            if (threadIdx.x == 0)
+                s_go = (open_early || chain_wait(a.bar, f - a.f0, G, a.timeout_ticks, a.abort_all)) ? 1u : 0u;
+            __syncthreads();
+            if (s_go == 0u) {  // workgroup-uniform
+                err |= kErrBarrier;
+                break;
+            }
+        }
+        SFM_CSTAMP(1);
+        for (uint32_t t0 = 0; t0 < mine || t0 == 0; t0 += kAccIter) {
+            if (t0) {
+#pragma unroll
+                for (int j = 0; j < kAccIter; j++) {
+                    pixv[j] = (((t0 + (uint32_t)j) * kChainWaves + w) * G + b) * kWave + lane;
+                    inv[j] = t0 + (uint32_t)j < mine && pixv[j] < npx;
+                    const uint32_t pa = inv[j] ? pixv[j] : 0u;
+                    infov[j] = (uint32_t)ldg(V.info + pa);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) h[j][q] = nl ? ldg(V.hits + (size_t)min((uint32_t)q, ql) * npx + pa) : kNoHit;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kAccIter; j++) infov[j] = inv[j] ? infov[j] : 0u;
+            // mask == 0 (:100) for the pixels that reach geometric_check; only those lanes ask
+            uint32_t mv[kAccIter];
+#pragma unroll
+            for (int j = 0; j < kAccIter; j++) {
+                mv[j] = 255u;
+                if (infov[j] & kVCand) mv[j] = mask_load_coherent(F.mask + pixv[j]);
+            }
+            bool acc[kAccIter];
+            unsigned pos[kAccIter];
+#pragma unroll
+            for (int j = 0; j < kAccIter; j++) {
+                const bool live = (infov[j] & kVCand) && mv[j] == 0u;
+                acc[j] = live && (infov[j] & kVOk);
+                c_gather += live ? (infov[j] & 63u) : 0u;
+                c_hit += acc[j] ? ((infov[j] >> 6) & 63u) : 0u;
+                if (acc[j] && (infov[j] & kVKeyRange)) err |= kErrKeyRange;
+                const unsigned long long m = __ballot(acc[j]);
+                pos[j] = (unsigned)__popcll(m & lanemask_lt());
+                if (lane == 0) s_wave[j * kChainWaves + w] = (unsigned)__popcll(m);
+            }
+            // the marks (:152-154) of the accepted pixels, into the masks of keyframes still to come: the first four
+            // later neighbours from the registers ...
+#pragma unroll
+            for (int j = 0; j < kAccIter; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit) mask_store_coherent(V.later_mask[q] + h[j][q]);
+            // ... the others four at a time (unconditional loads: a lane without an accepted pixel reads element 0)
+            for (uint32_t s0 = 4; s0 < nl; s0 += 4) {
+                uint32_t h2[kAccIter][4];
+#pragma unroll
+                for (int j = 0; j < kAccIter; j++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        h2[j][q] = ldg(V.hits + (size_t)min(s0 + (uint32_t)q, nl - 1u) * npx + (acc[j] ? pixv[j] : 0u));
+#pragma unroll
+                for (int j = 0; j < kAccIter; j++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (acc[j] && s0 + (uint32_t)q < nl && h2[j][q] != kNoHit)
+                            mask_store_coherent(V.later_mask[s0 + q] + h2[j][q]);
+            }
+            // the accepted pixels' fused points: requested now, so that their (cold, scattered) round trip runs under the
+            // wait for the marks' acknowledgement instead of behind the barrier arrival (unconditional loads)
+            VerdictRec rv[kAccIter];
+#pragma unroll
+            for (int j = 0; j < kAccIter; j++) {
+                const VerdictRec *rp = V.rec + (acc[j] ? pixv[j] : 0u);
+                typedef unsigned long long ull2_t __attribute__((ext_vector_type(2)));
+                const ull2_t k0 = *(const __attribute__((address_space(1))) ull2_t *)rp;
+                const ull2_t k1 = *((const __attribute__((address_space(1))) ull2_t *)rp + 1);
+                rv[j].key = k0.x;
+                rv[j].x = __longlong_as_double((long long)k0.y);
+                rv[j].y = __longlong_as_double((long long)k1.x);
+                rv[j].z = __longlong_as_double((long long)k1.y);
+            }
+            SFM_CSTAMP(3);
+            __syncthreads();
+            SFM_CSTAMP(2);
+            // list space for the pass: wave 0 scans the 64 per-wave counts, one atomic per workgroup
+            if (w == 0) {
+                const unsigned cnt = s_wave[lane];
+                unsigned inc = cnt;
+                for (int o = 1; o < kWave; o <<= 1) {
+                    const unsigned t = __shfl_up(inc, o);
+                    if ((int)lane >= o) inc += t;
+                }
+                s_off[lane] = inc - cnt;
+                if (lane == kWave - 1)
+                    s_base = inc ? atomicAdd(&a.list.cursor[(b % kListShards) * 8], (unsigned long long)inc) : 0ull;
+            }
+            // The barrier only orders the mask stores: after the keyframe's last pass the workgroup arrives as soon
+            // as its stores are acknowledged, and writes its records while the others arrive.
+            const bool last = t0 + kAccIter >= mine;
+            if (last && f + 1 < a.f1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) chain_arrive(a.bar, G, f - a.f0 + 1);
+                SFM_CSTAMP(6);
+            } else {
+                __syncthreads();
+            }
+            const unsigned long long base = s_base;
+#pragma unroll
+            for (int j = 0; j < kAccIter; j++) {
+                if (acc[j]) {
+                    const unsigned long long rel = base + s_off[j * kChainWaves + w] + pos[j];
+                    if (rel < a.list.shard_cap) {
+                        const unsigned long long idx = (unsigned long long)(b % kListShards) * a.list.shard_cap + rel;
+                        const VerdictRec r = rv[j];
+                        a.list.tag[idx] = (infov[j] & kVKeyRange) ? kEmpty : (((unsigned long long)F.order << 32) | pixv[j]);
+                        a.list.key[idx] = r.key;
+                        a.list.xyz[3 * idx + 0] = r.x;
+                        a.list.xyz[3 * idx + 1] = r.y;
+                        a.list.xyz[3 * idx + 2] = r.z;
+                    } else {
+                        err |= kErrListFull;
+                    }
+                }
+            }
+            if (STAMPS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SFM_CSTAMP(4);
+            __syncthreads();  // s_wave and s_base are reused by the next pass / keyframe
+            if (mine == 0) break;
+        }
+    }
+    if (threadIdx.x == 0) {  // list boundaries of the group, as in fuse_chain_kernel
+        const unsigned left = __hip_atomic_fetch_add(a.bar + kBarDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == G - 1u) {
+            unsigned long long *ge = a.list.group_end + (size_t)a.group * kListShards * 8;
+            for (int sh = 0; sh < kListShards; sh++)
+                ge[sh * 8] = __hip_atomic_load(a.list.cursor + sh * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    c_gather = wave_sum(c_gather);
+    c_hit = wave_sum(c_hit);
+    const unsigned any_err = (unsigned)__builtin_amdgcn_readfirstlane((int)(__ballot(err != 0) != 0ull));
+    if (any_err) {
+        for (int o = 32; o > 0; o >>= 1) err |= __shfl_xor(err, o);
+    }
+    if (lane == 0 && (c_gather | c_hit | err)) {
+        StatShard *st = &a.stat[(b * kChainWaves + w) % kStatShards];
+        if (c_gather) atomicAdd(&st->n_gather, (unsigned long long)c_gather);
+        if (c_hit) atomicAdd(&st->n_hit, (unsigned long long)c_hit);
+        if (err) atomicOr(&st->err, err);
+    }
+}
+
+__global__ __launch_bounds__(kChainThreads) void accept_chain_kernel(const FrameDev *__restrict__ frames,
+                                                                     const VerdictDev *__restrict__ verdicts, AcceptArgs aa)
+{
+    accept_chain_body<false>(frames, verdicts, aa);
+}
+
+#if SFM_STAMPS
+__global__ __launch_bounds__(kChainThreads) void accept_chain_kernel_stamps(const FrameDev *__restrict__ frames,
+                                                                            const VerdictDev *__restrict__ verdicts,
+                                                                            AcceptArgs aa)
+{
+    accept_chain_body<true>(frames, verdicts, aa);
 }
 #endif
 

@@ -145,8 +145,11 @@ class SequenceSplit:
     import_masks(first, count, ptr, nbytes), run(), export_masks(first, count, ptr, nbytes) -- sfm_amd.fusion.
     FusionContext on a GPU, an oracle-backed stand-in in the CPU tests.  `px` maps a global keyframe to W*H."""
 
-    def __init__(self, ctx, plan: RankPlan, px, rank: int, world: int, device, group=None):
+    def __init__(self, ctx, plan: RankPlan, px, rank: int, world: int, device, group=None, precompute=None):
         self.ctx, self.plan, self.px = ctx, plan, px
+        # two-phase chain on the ranks that wait: their mask-independent verdicts (sfm_fusion_precompute) are
+        # computed while the ranks before them chain; the first rank has nobody to wait for and runs the fused chain
+        self.precompute = (rank > 0 and hasattr(ctx, "precompute")) if precompute is None else precompute
         self.rank, self.world, self.device, self.group = rank, world, device, group
         self.bytes_sent = 0
         self.bytes_received = 0
@@ -157,6 +160,8 @@ class SequenceSplit:
     def run(self):
         ctx, plan = self.ctx, self.plan
         ctx.clear_imported_masks()
+        if self.precompute:
+            ctx.precompute()  # asynchronous: overlaps the wait for the predecessors' masks
         for q, frames in plan.recvs.items():  # ascending ranks: the order the senders finish in
             n = sum(self.px(g) for g in frames)
             buf = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)

@@ -38,7 +38,7 @@ EXPORTS = [
     "sfm_fusion_set_profiling", "sfm_fusion_set_global_order", "sfm_fusion_partition_counts",
     "sfm_fusion_export_records", "sfm_fusion_merge", "sfm_fusion_set_covisibility",
     "sfm_fusion_partition_counts_noalloc", "sfm_fusion_set_active_range", "sfm_fusion_import_masks",
-    "sfm_fusion_clear_imported_masks", "sfm_fusion_export_masks",
+    "sfm_fusion_clear_imported_masks", "sfm_fusion_export_masks", "sfm_fusion_precompute",
 ]
 SFM_RECORD_BYTES = 48
 
@@ -61,7 +61,8 @@ class FusionStats(C.Structure):
         ("table_used", C.c_uint64), ("max_probe", C.c_uint64),
         ("last_run_ms", C.c_double), ("frame_kernels_ms", C.c_double),
         ("fuse_kernel_launches", C.c_uint64), ("fuse_kernel_sum_ms", C.c_double),
-        ("scan_kernel_sum_ms", C.c_double), ("fused_chain", C.c_uint64), ("chain_fallbacks", C.c_uint64),
+        ("scan_kernel_sum_ms", C.c_double), ("fused_chain", C.c_uint64), ("precomputed", C.c_uint64),
+        ("precompute_ms", C.c_double), ("chain_fallbacks", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -112,6 +113,7 @@ def load_library():
     L.sfm_fusion_import_masks.argtypes = [vp, u32, u32, vp, u64]
     L.sfm_fusion_clear_imported_masks.argtypes = [vp]
     L.sfm_fusion_export_masks.argtypes = [vp, u32, u32, vp, u64]
+    L.sfm_fusion_precompute.argtypes = [vp]
     L.sfm_fusion_last_error.argtypes = [vp]
     L.sfm_fusion_last_error.restype = C.c_char_p
     L.sfm_fusion_version.restype = C.c_char_p
@@ -234,6 +236,10 @@ class FusionContext:
 
     def merge(self, records_ptr: int, n: int):
         self._check(self._L.sfm_fusion_merge(self._h, C.c_void_p(records_ptr), n))
+
+    def precompute(self):
+        """Phase A of the two-phase chain: the mask-independent verdicts of the active keyframes (asynchronous)."""
+        self._check(self._L.sfm_fusion_precompute(self._h))
 
     def set_active_range(self, first: int, end: int):
         """Only keyframes [first, end) are fused by this ctx (one sequence over several GPUs)."""

@@ -34,7 +34,7 @@ def test_default_params_match_the_reference_constants():
 
 def test_struct_sizes_match_the_header():
     assert ctypes.sizeof(fusion.FusionParams) == 11 * 8 + 2 * 8
-    assert ctypes.sizeof(fusion.FusionStats) == 11 * 8 + 2 * 8 + 8 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(fusion.FusionStats) == 11 * 8 + 2 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
     assert fusion.SFM_RECORD_BYTES == 48
 
 

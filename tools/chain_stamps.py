@@ -4,11 +4,12 @@ group SFM_STAMP_GROUP) from the -DSFM_STAMPS=1 build.  Run on the GPU box: pytho
 import os, subprocess, sys
 import numpy as np
 group = sys.argv[1] if len(sys.argv) > 1 else "9"
+extra = sys.argv[2:]  # passed on to bench.py, e.g. --two-phase --workload c3_2000kf_1280x720_1cm
 out = "gpurun_out/cstamps_%s.bin" % group
 os.makedirs("gpurun_out", exist_ok=True)
 env = dict(os.environ, SFM_FUSION_LIB=os.path.abspath(os.environ.get("SFM_STAMPS_LIB", "build/stamps/libsfm_fusion_stamps.so")),
            SFM_STAMP_GROUP=group, SFM_STAMP_OUT=out)
-subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env,
+subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + extra, env=env,
                check=True, stdout=subprocess.DEVNULL)
 raw = np.fromfile(out, dtype=np.uint64).astype(np.int64)
 G = raw.size // (32 * 16)
