@@ -111,6 +111,21 @@ int sfm_fusion_add_keyframe(sfm_fusion_ctx *ctx, uint32_t order_idx, int32_t W, 
                             const double K[4], const double T_wk[16], const double T_kw[16],
                             int mem_kind);
 
+/* The same keyframe with its pose straight from the bundle-adjustment result: the 6-vector that
+ * Map::local_bundle_adjustment optimises, written back as
+ *     Eigen::Matrix4d tf = Sophus::SE3<double>::exp(se3_vec).matrix();  kf->set_world_to_camera(tf);
+ * (src/map.cpp:321-324; set_world_to_camera stores T_kw = tf and T_wk = tf.inverse(), src/keyframe.cpp:56-60).
+ * se3_kw = (upsilon[3], omega[3]) in Sophus' tangent order.  sfm_fusion_se3_exp is the conversion by itself
+ * (column-major 4x4 out; either output may be NULL).  Parity note: exp follows Sophus' published formulas; the
+ * inverse is the rigid inverse [R^T | -R^T t], whereas the reference calls Eigen's general 4x4 inverse -- the two
+ * agree to rounding, not bit for bit.  A caller that needs the reference's exact bits passes both matrices to
+ * sfm_fusion_add_keyframe, as the facade does. */
+int sfm_fusion_add_keyframe_se3(sfm_fusion_ctx *ctx, uint32_t order_idx, int32_t W, int32_t H,
+                                const uint16_t *depth, size_t depth_stride_bytes,
+                                const uint8_t *bgr, size_t bgr_stride_bytes,
+                                const double K[4], const double se3_kw[6], int mem_kind);
+void sfm_fusion_se3_exp(const double se3[6], double T[16], double T_inv[16]);
+
 /* Map::get_neighbors(kf, 100) (src/map.cpp:152-160) as order indices, in the order the
  * reference would iterate them.  The distance/direction filter of process_frame
  * (src/dense_reconstruction.cpp:72-89) is applied inside the library. */

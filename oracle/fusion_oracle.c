@@ -111,6 +111,19 @@ void orc_default_params(orc_params *p)
 
 /* ---- small fixed-size algebra in Eigen's evaluation order -------------------------- */
 
+/* Evaluation-order VARIANTS (tests/test_oracle_variants.py, tools/oracle_order_risk.py).  Eigen is absent from this
+ * image, so the orders above are restated from its sources and cannot be checked against the real binary; these
+ * switches rebuild the oracle with the plausible alternatives so that the risk is a measured number: how many voxel
+ * keys, winners and coordinate bits change.  0 (the default) is the oracle; nothing else is ever used as a checker.
+ *   1  trace() = (d0 + d1) + d2               instead of d0 + (d1 + d2)
+ *   2  T*[p;1] row = (m0*x + (m1*y + m2*z)) + m3   instead of ((m0*x + m1*y) + m2*z) + m3
+ *   4  3x3 product coefficient = (a0*b0 + a1*b1) + a2*b2   instead of a0*b0 + (a1*b1 + a2*b2)
+ *   8  FMA contraction (what -march=native / -ffp-contract=fast would allow) in the products and sums above,
+ *      in the projection (x/z)*f + c, in norm() and in the weighted sums */
+static int g_variant = 0;
+void orc_set_variant(int flags) { g_variant = flags; }
+int orc_get_variant(void) { return g_variant; }
+
 /* C = A*B, 3x3 row-major arrays, coefficient = a0*b0 + (a1*b1 + a2*b2). */
 static void mat3_mul(const double A[9], const double B[9], double C[9])
 {
@@ -119,7 +132,14 @@ static void mat3_mul(const double A[9], const double B[9], double C[9])
             double t0 = A[i * 3 + 0] * B[0 * 3 + j];
             double t1 = A[i * 3 + 1] * B[1 * 3 + j];
             double t2 = A[i * 3 + 2] * B[2 * 3 + j];
-            C[i * 3 + j] = t0 + (t1 + t2);
+            if (g_variant & 8) {
+                if (g_variant & 4) C[i * 3 + j] = fma(A[i * 3 + 2], B[2 * 3 + j], fma(A[i * 3 + 1], B[1 * 3 + j], t0));
+                else C[i * 3 + j] = fma(A[i * 3 + 0], B[0 * 3 + j], fma(A[i * 3 + 1], B[1 * 3 + j], t2));
+            } else if (g_variant & 4) {
+                C[i * 3 + j] = (t0 + t1) + t2;
+            } else {
+                C[i * 3 + j] = t0 + (t1 + t2);
+            }
         }
 }
 
@@ -127,10 +147,19 @@ static void mat3_mul(const double A[9], const double B[9], double C[9])
 static void mat4_apply(const double T[16], const double p[3], double out[3])
 {
     for (int r = 0; r < 3; r++) {
-        double acc = T[r + 0] * p[0];
-        acc = acc + T[r + 4] * p[1];
-        acc = acc + T[r + 8] * p[2];
-        out[r] = acc + T[r + 12];
+        if (g_variant & 8) {
+            double acc = T[r + 0] * p[0];
+            if (g_variant & 2) acc = fma(T[r + 0], p[0], fma(T[r + 4], p[1], T[r + 8] * p[2]));
+            else acc = fma(T[r + 8], p[2], fma(T[r + 4], p[1], acc));
+            out[r] = acc + T[r + 12];
+        } else if (g_variant & 2) {
+            out[r] = (T[r + 0] * p[0] + (T[r + 4] * p[1] + T[r + 8] * p[2])) + T[r + 12];
+        } else {
+            double acc = T[r + 0] * p[0];
+            acc = acc + T[r + 4] * p[1];
+            acc = acc + T[r + 8] * p[2];
+            out[r] = acc + T[r + 12];
+        }
     }
 }
 
@@ -151,6 +180,7 @@ double orc_cov_trace(const orc_params *p, int u, int v, double d, double focal_l
             Jt[i * 3 + j] = J[j * 3 + i];
     mat3_mul(J, S, M);
     mat3_mul(M, Jt, P);
+    if (g_variant & 1) return (P[0] + P[4]) + P[8];
     return P[0] + (P[4] + P[8]);
 }
 
@@ -170,8 +200,13 @@ void orc_project(const double K[4], const double T_kw[16], const double pw[3],
 {
     double c[3];
     mat4_apply(T_kw, pw, c);
-    *px = (c[0] / c[2]) * K[0] + K[2];
-    *py = (c[1] / c[2]) * K[1] + K[3];
+    if (g_variant & 8) {
+        *px = fma(c[0] / c[2], K[0], K[2]);
+        *py = fma(c[1] / c[2], K[1], K[3]);
+    } else {
+        *px = (c[0] / c[2]) * K[0] + K[2];
+        *py = (c[1] / c[2]) * K[1] + K[3];
+    }
     *cz = c[2];
 }
 
@@ -284,7 +319,7 @@ static int process_pixel(const orc_params *P, const orc_frame *frames, uint8_t *
         double dx = obs_p[3 * i + 0] - pw[0];
         double dy = obs_p[3 * i + 1] - pw[1];
         double dz = obs_p[3 * i + 2] - pw[2];
-        double n = sqrt((dx * dx + dy * dy) + dz * dz);
+        double n = (g_variant & 8) ? sqrt(fma(dz, dz, fma(dy, dy, dx * dx))) : sqrt((dx * dx + dy * dy) + dz * dz);
         if (n < P->T_dist) close_count++;
     }
     if ((double)close_count < (double)n_obs * P->close_frac) { ctr->n_rej_far++; return 0; } /* :229 */
@@ -296,9 +331,15 @@ static int process_pixel(const orc_params *P, const orc_frame *frames, uint8_t *
     double wp[3] = { 0, 0, 0 }, total = 0;                           /* :158-165 */
     for (uint32_t i = 0; i < n_obs; i++) {
         double inv = 1.0 / obs_w[i];
+        if (g_variant & 8) {
+            wp[0] = fma(obs_p[3 * i + 0], inv, wp[0]);
+            wp[1] = fma(obs_p[3 * i + 1], inv, wp[1]);
+            wp[2] = fma(obs_p[3 * i + 2], inv, wp[2]);
+        } else {
         wp[0] = wp[0] + obs_p[3 * i + 0] * inv;
         wp[1] = wp[1] + obs_p[3 * i + 1] * inv;
         wp[2] = wp[2] + obs_p[3 * i + 2] * inv;
+        }
         total = total + 1.0 / obs_w[i];
     }
     out->p[0] = wp[0] / total;

@@ -108,6 +108,9 @@ def lib():
                                   C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(OrcResult)]
         L.orc_fuse_ex.restype = C.c_int
         L.orc_free_result.argtypes = [C.POINTER(OrcResult)]
+        L.orc_set_variant.argtypes = [C.c_int]
+        L.orc_set_variant.restype = None
+        L.orc_get_variant.restype = C.c_int
         _lib = L
     return _lib
 
@@ -248,6 +251,23 @@ def fuse(frames, params=None, n_threads: int = 1, active=None, mask_seed=None, w
         return (cloud, masks_out) if want_masks else cloud
     finally:
         lib().orc_free_result(C.byref(res))
+
+
+class variant:
+    """Context manager: run the oracle with alternative Eigen evaluation orders / FMA contraction (flags in
+    fusion_oracle.c).  Only for measuring how much the unverifiable choices matter; flags 0 is the oracle."""
+
+    def __init__(self, flags: int):
+        self.flags = int(flags)
+
+    def __enter__(self):
+        self.prev = lib().orc_get_variant()
+        lib().orc_set_variant(self.flags)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_variant(self.prev)
+        return False
 
 
 def algorithmic_bytes(c: dict) -> int:

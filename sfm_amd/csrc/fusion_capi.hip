@@ -958,6 +958,78 @@ int sfm_fusion_add_keyframe(sfm_fusion_ctx *c, uint32_t order_idx, int32_t W, in
     return SFM_OK;
 }
 
+// Sophus::SE3<double>::exp(tangent).matrix() and its inverse, column-major.  Tangent order as in Sophus:
+// (upsilon = translational part, omega = rotation vector).  Restated from Sophus' published formulas
+// (so3.hpp expAndTheta: unit quaternion from the half angle, Taylor branch below |omega| < 1e-10; se3.hpp exp:
+// t = V * upsilon, V = I + (1 - cos th)/th^2 * Om + (th - sin th)/th^3 * Om^2; Eigen's Quaternion::toRotationMatrix).
+void sfm_fusion_se3_exp(const double se3[6], double T[16], double T_inv[16])
+{
+    const double ux = se3[0], uy = se3[1], uz = se3[2], wx = se3[3], wy = se3[4], wz = se3[5];
+    const double theta_sq = wx * wx + wy * wy + wz * wz;
+    const double eps = 1e-10;
+    double theta, imag, real;
+    if (theta_sq < eps * eps) {
+        theta = 0.0;
+        const double theta_po4 = theta_sq * theta_sq;
+        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
+        real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
+    } else {
+        theta = std::sqrt(theta_sq);
+        const double half = 0.5 * theta;
+        imag = std::sin(half) / theta;
+        real = std::cos(half);
+    }
+    const double qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
+    // Eigen::Quaternion::toRotationMatrix
+    const double tx = 2.0 * qx, ty = 2.0 * qy, tz = 2.0 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw;
+    const double txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    double R[3][3];
+    R[0][0] = 1.0 - (tyy + tzz); R[0][1] = txy - twz;         R[0][2] = txz + twy;
+    R[1][0] = txy + twz;         R[1][1] = 1.0 - (txx + tzz); R[1][2] = tyz - twx;
+    R[2][0] = txz - twy;         R[2][1] = tyz + twx;         R[2][2] = 1.0 - (txx + tyy);
+    double V[3][3];
+    if (std::fabs(theta) < eps) {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) V[i][j] = R[i][j];  // "an accurate expansion" (se3.hpp)
+    } else {
+        const double Om[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+        double Om2[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Om2[i][j] = Om[i][0] * Om[0][j] + Om[i][1] * Om[1][j] + Om[i][2] * Om[2][j];
+        const double a = (1.0 - std::cos(theta)) / theta_sq;
+        const double b = (theta - std::sin(theta)) / (theta_sq * theta);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) V[i][j] = (i == j ? 1.0 : 0.0) + a * Om[i][j] + b * Om2[i][j];
+    }
+    const double t[3] = {V[0][0] * ux + V[0][1] * uy + V[0][2] * uz, V[1][0] * ux + V[1][1] * uy + V[1][2] * uz,
+                         V[2][0] * ux + V[2][1] * uy + V[2][2] * uz};
+    if (T) {
+        for (int col = 0; col < 3; col++)
+            for (int r = 0; r < 3; r++) T[r + 4 * col] = R[r][col];
+        T[12] = t[0]; T[13] = t[1]; T[14] = t[2];
+        T[3] = T[7] = T[11] = 0.0; T[15] = 1.0;
+    }
+    if (T_inv) {  // rigid inverse [R^T | -R^T t]
+        for (int col = 0; col < 3; col++)
+            for (int r = 0; r < 3; r++) T_inv[r + 4 * col] = R[col][r];
+        for (int r = 0; r < 3; r++) T_inv[12 + r] = -(R[0][r] * t[0] + R[1][r] * t[1] + R[2][r] * t[2]);
+        T_inv[3] = T_inv[7] = T_inv[11] = 0.0; T_inv[15] = 1.0;
+    }
+}
+
+int sfm_fusion_add_keyframe_se3(sfm_fusion_ctx *c, uint32_t order_idx, int32_t W, int32_t H, const uint16_t *depth,
+                                size_t depth_stride, const uint8_t *bgr, size_t bgr_stride, const double K[4],
+                                const double se3_kw[6], int mem_kind)
+{
+    if (!c) return SFM_E_INVALID;
+    if (!se3_kw) return fail(c, SFM_E_INVALID, "null pose");
+    double T_kw[16], T_wk[16];
+    sfm_fusion_se3_exp(se3_kw, T_kw, T_wk);  // set_world_to_camera(tf): T_kw = tf, T_wk = tf.inverse()  (keyframe.cpp:56-60)
+    return sfm_fusion_add_keyframe(c, order_idx, W, H, depth, depth_stride, bgr, bgr_stride, K, T_wk, T_kw, mem_kind);
+}
+
 int sfm_fusion_set_neighbors(sfm_fusion_ctx *c, uint32_t order_idx, const uint32_t *nbr, uint32_t n)
 {
     if (!c) return SFM_E_INVALID;

@@ -39,6 +39,7 @@ EXPORTS = [
     "sfm_fusion_export_records", "sfm_fusion_merge", "sfm_fusion_set_covisibility",
     "sfm_fusion_partition_counts_noalloc", "sfm_fusion_set_active_range", "sfm_fusion_import_masks",
     "sfm_fusion_clear_imported_masks", "sfm_fusion_export_masks", "sfm_fusion_precompute",
+    "sfm_fusion_add_keyframe_se3", "sfm_fusion_se3_exp",
 ]
 SFM_RECORD_BYTES = 48
 
@@ -96,6 +97,9 @@ def load_library():
     L.sfm_fusion_destroy.argtypes = [vp]
     L.sfm_fusion_destroy.restype = None
     L.sfm_fusion_add_keyframe.argtypes = [vp, u32, i32, i32, vp, C.c_size_t, vp, C.c_size_t, dp, dp, dp, C.c_int]
+    L.sfm_fusion_add_keyframe_se3.argtypes = [vp, u32, i32, i32, vp, C.c_size_t, vp, C.c_size_t, dp, dp, C.c_int]
+    L.sfm_fusion_se3_exp.argtypes = [dp, dp, dp]
+    L.sfm_fusion_se3_exp.restype = None
     L.sfm_fusion_set_neighbors.argtypes = [vp, u32, C.POINTER(u32), u32]
     L.sfm_fusion_set_covisibility.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), u64, u32, u32]
     L.sfm_fusion_run.argtypes = [vp]
@@ -132,6 +136,17 @@ def default_params(**over) -> FusionParams:
                 raise KeyError(k)
             setattr(p, k, v)
     return p
+
+
+def se3_exp(se3):
+    """Sophus::SE3<double>::exp(se3).matrix() and its inverse as (4,4) arrays; se3 = (upsilon, omega)
+    (the bundle-adjustment write-back, reference src/map.cpp:321-324)."""
+    v = np.ascontiguousarray(se3, dtype=np.float64).reshape(6)
+    T = np.zeros(16)
+    Ti = np.zeros(16)
+    dp = C.POINTER(C.c_double)
+    load_library().sfm_fusion_se3_exp(v.ctypes.data_as(dp), T.ctypes.data_as(dp), Ti.ctypes.data_as(dp))
+    return T.reshape(4, 4).T.copy(), Ti.reshape(4, 4).T.copy()
 
 
 def _colmajor16(T):
@@ -185,6 +200,20 @@ class FusionContext:
             self._h, self.n_frames, W, H, depth.ctypes.data, depth.strides[0] if H else 2 * W,
             bgr.ctypes.data, bgr.strides[0] if H else 3 * W,
             Kc.ctypes.data_as(dp), a.ctypes.data_as(dp), b.ctypes.data_as(dp), SFM_MEM_HOST))
+        self.n_frames += 1
+        return self.n_frames - 1
+
+    def add_keyframe_se3(self, depth, bgr, K, se3_kw):
+        """Host images, pose as the 6-vector of the bundle adjustment (T_kw = SE3::exp(se3_kw))."""
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        H, W = depth.shape
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        v = np.ascontiguousarray(se3_kw, dtype=np.float64).reshape(6)
+        dp = C.POINTER(C.c_double)
+        self._check(self._L.sfm_fusion_add_keyframe_se3(
+            self._h, self.n_frames, W, H, depth.ctypes.data, 2 * W, bgr.ctypes.data, 3 * W,
+            Kc.ctypes.data_as(dp), v.ctypes.data_as(dp), SFM_MEM_HOST))
         self.n_frames += 1
         return self.n_frames - 1
 

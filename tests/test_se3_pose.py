@@ -1,0 +1,81 @@
+"""sfm_fusion_se3_exp, the pose conversion of the bundle-adjustment write-back (reference src/map.cpp:321-324:
+tf = Sophus::SE3<double>::exp(se3_vec).matrix()), against the matrix exponential of the twist and against
+closed-form known answers.  Host-only code of the library: runs without a GPU."""
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+from sfm_amd import fusion
+
+
+def twist(se3):
+    u, w = np.asarray(se3[:3], float), np.asarray(se3[3:], float)
+    M = np.zeros((4, 4))
+    M[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+    M[:3, 3] = u
+    return M
+
+
+def test_known_answers():
+    T, Ti = fusion.se3_exp([1.5, -2.0, 0.25, 0, 0, 0])              # pure translation
+    assert np.array_equal(T, np.array([[1, 0, 0, 1.5], [0, 1, 0, -2.0], [0, 0, 1, 0.25], [0, 0, 0, 1.0]]))
+    assert np.array_equal(Ti[:3, 3], [-1.5, 2.0, -0.25])
+    T, _ = fusion.se3_exp([0, 0, 0, 0, 0, np.pi / 2])              # quarter turn about z
+    assert np.allclose(T[:3, :3], [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-15) and np.array_equal(T[:3, 3], [0, 0, 0])
+    # a screw along z: translation along the axis is untouched, the in-plane part follows V
+    th = 0.7
+    T, _ = fusion.se3_exp([1.0, 0.0, 2.0, 0, 0, th])
+    assert np.allclose(T[:3, 3], [np.sin(th) / th, (1 - np.cos(th)) / th, 2.0], rtol=0, atol=1e-15)
+
+
+def test_against_the_matrix_exponential():
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        se3 = np.concatenate([rng.normal(0, 3.0, 3), rng.normal(0, 1.2, 3)])
+        T, Ti = fusion.se3_exp(se3)
+        assert np.allclose(T, expm(twist(se3)), rtol=0, atol=5e-13)
+        assert np.allclose(T @ Ti, np.eye(4), rtol=0, atol=5e-13)
+        R = T[:3, :3]
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-14) and abs(np.linalg.det(R) - 1) < 1e-14
+        assert np.array_equal(T[3], [0, 0, 0, 1]) and np.array_equal(Ti[3], [0, 0, 0, 1])
+
+
+def test_small_angle_branch():
+    for w in (0.0, 1e-12, 9.9e-11, 1.1e-10, 1e-8, 1e-5):
+        se3 = np.array([0.3, -0.1, 0.7, w, -w / 2, w / 3])
+        T, _ = fusion.se3_exp(se3)
+        # below |omega| = 1e-10 Sophus takes V = R (first order in the angle): the error is of the angle's size
+        assert np.allclose(T, expm(twist(se3)), rtol=0, atol=2e-10 if w < 1.05e-10 else 1e-14)
+
+
+@pytest.mark.gpu
+def test_add_keyframe_se3_equals_add_keyframe_with_the_converted_matrices():
+    from scipy.spatial.transform import Rotation
+    from sfm_amd import synth
+    seq = synth.make_sequence(5, 64, 48, K=(131.25, 131.25, 31.5, 23.5), window=2)
+    frames = seq.frame_dicts()
+    gp = fusion.default_params(voxel_size=30.0, T_dist=500.0)
+    clouds = []
+    for use_se3 in (True, False):
+        ctx = fusion.FusionContext(gp)
+        for f in frames:
+            # the keyframe's world->camera pose as a tangent vector: log of the rotation, V^-1 t by solving V u = t
+            rv = Rotation.from_matrix(f["T_kw"][:3, :3]).as_rotvec()
+            V = fusion.se3_exp(np.concatenate([[0, 0, 0], rv]))[0][:3, :3]
+            th = np.linalg.norm(rv)
+            Om = twist(np.concatenate([[0, 0, 0], rv]))[:3, :3]
+            Vm = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (th - np.sin(th)) / th ** 3 * Om @ Om
+            se3 = np.concatenate([np.linalg.solve(Vm, f["T_kw"][:3, 3]), rv])
+            if use_se3:
+                ctx.add_keyframe_se3(f["depth"], f["bgr"], f["K"], se3)
+            else:
+                T_kw, T_wk = fusion.se3_exp(se3)
+                ctx.add_keyframe(f["depth"], f["bgr"], f["K"], T_wk, T_kw)
+        for i, f in enumerate(frames):
+            ctx.set_neighbors(i, f["nbrs"])
+        ctx.run()
+        clouds.append(ctx.read_points())
+        ctx.close()
+    assert clouds[0][2].shape[0] > 500
+    for a, b in zip(*clouds):
+        assert np.array_equal(a, b)
