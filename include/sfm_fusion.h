@@ -35,13 +35,15 @@ extern "C" {
 #define SFM_E_TABLE_FULL (-3)  /* voxel table capacity exhausted */
 #define SFM_E_KEY_RANGE (-4)   /* a voxel index does not fit the packed 3x21-bit key */
 #define SFM_E_CAPACITY (-5)    /* accepted-point list capacity exhausted */
-#define SFM_E_UNSUPPORTED (-6) /* e.g. more than SFM_MAX_NEIGHBORS filtered neighbours */
+#define SFM_E_UNSUPPORTED (-6) /* e.g. more than 4095 filtered neighbours of one keyframe */
 #define SFM_E_NOMEM (-7)
 
 #define SFM_MEM_HOST 0   /* pointers are host memory   */
 #define SFM_MEM_DEVICE 1 /* pointers are device memory on the ctx's GPU */
 
-#define SFM_MAX_NEIGHBORS 32 /* filtered neighbours per keyframe handled by the kernels */
+#define SFM_MAX_NEIGHBORS 32 /* filtered neighbours per keyframe that the fused kernels hold on chip; a keyframe with
+                              * more (the reference has no cap, src/map.cpp:152-160) sends the run through the
+                              * two-phase chain of sfm_fusion_precompute, whose neighbours are a loop: same cloud */
 
 typedef struct sfm_fusion_ctx sfm_fusion_ctx;
 

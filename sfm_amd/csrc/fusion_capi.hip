@@ -184,7 +184,9 @@ struct sfm_fusion_ctx {
     std::vector<uint32_t> h_nbr;       // filtered neighbours of every keyframe, back to back (FrameDev::nbr_begin)
     DevBuf<unsigned char> d_verdict_arena;
     DevBuf<VerdictDev> d_verdicts;
+    DevBuf<uint8_t *> d_later_masks;   // masks of every active keyframe's later neighbours (VerdictDev::later_begin)
     bool have_verdicts = false;
+    bool big_k = false;                // a keyframe has more filtered neighbours than the fused kernels hold (kMaxK)
     bool auto_precompute = false;      // SFM_PRECOMPUTE=1: every run goes through the two phases (tests)
     bool verdicts_ran = false;
     hipEvent_t ev_pa[2] = {nullptr, nullptr};  // around phase A's launches
@@ -352,6 +354,7 @@ int build_layout(sfm_fusion_ctx *c)
     std::vector<FrameDev> &fd = c->h_frames;
     fd.assign(n, FrameDev());
     c->have_verdicts = false;
+    c->big_k = false;
     std::vector<uint32_t> &nbr = c->h_nbr;
     nbr.clear();
     // lookup tables, one per distinct (f, c, extent) / focal length
@@ -425,11 +428,12 @@ int build_layout(sfm_fusion_ctx *c)
         f.n_filtered = d.nbr_count;
         d.order = (uint32_t)i;
         d.pad = 0;
-        if (d.nbr_count > SFM_MAX_NEIGHBORS)
+        // more neighbours than the fused kernels hold in LDS take the two-phase chain, whose neighbours are a loop
+        if (d.nbr_count > (uint32_t)kMaxK) c->big_k = true;
+        if (d.nbr_count > (uint32_t)kMaxKTwoPhase)
             return fail(c, SFM_E_UNSUPPORTED,
                         "keyframe " + std::to_string(i) + " has " + std::to_string(d.nbr_count) +
-                            " filtered neighbours; the kernels handle at most " +
-                            std::to_string(SFM_MAX_NEIGHBORS));
+                            " filtered neighbours; the per-pixel counters hold at most " + std::to_string(kMaxKTwoPhase));
     }
     std::vector<FrameDev> pack(nbr.size());
     for (size_t j = 0; j < nbr.size(); j++) pack[j] = fd[nbr[j]];
@@ -556,13 +560,38 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     for (size_t i = 0; use_chain && i < n; i++)
         if (!chain_div_ok(a.P, c->frames[i].K, c->frames[i].W, c->frames[i].H, c->h_frames[i].Twk, c->h_frames[i].Tkw))
             use_chain = false;
+    // with the verdicts of sfm_fusion_precompute the chain is accept_chain_kernel: no LDS slots, no divisions -- all it
+    // needs is the device-wide barrier; without that it is launched keyframe by keyframe
+    const bool use_verdicts = c->have_verdicts;
+    if (use_verdicts) use_chain = c->chain && c->chain_items > 0;
     c->chain_ran = use_chain;
-    const bool use_verdicts = use_chain && c->have_verdicts;
     c->verdicts_ran = use_verdicts;
     for (size_t g = 0; g < n_groups; g++) {
         const size_t g0 = a0 + g * kGroup, g1 = std::min(a1, g0 + kGroup);
         bool group_event_recorded = false;
-        if (use_chain) {
+        if (use_verdicts && !use_chain) {
+            // phase B without the device-wide barrier: one accept_chain_kernel launch per keyframe, the kernel
+            // boundary orders the marks
+            for (size_t i = g0; i < g1; i++) {
+                AcceptArgs aa;
+                aa.c.f0 = (uint32_t)i;
+                aa.c.f1 = (uint32_t)i + 1;
+                aa.c.item_cap = 0;
+                aa.c.group = 0xFFFFFFFFu;
+                aa.c.list = list;
+                aa.c.stat = dev_stat(c);
+                aa.c.bar = c->z_bar + g * kBarStride;
+                aa.c.P = a.P;
+                aa.c.abort_all = c->z_abort;
+                aa.c.timeout_ticks = c->chain_timeout_ticks;
+                aa.c.stamps = nullptr;
+                aa.v_first = (uint32_t)a0;
+                aa.pad = 0;
+                hipLaunchKernelGGL(accept_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), 0, sa,
+                                   (const FrameDev *)c->d_frames.p, (const VerdictDev *)c->d_verdicts.p,
+                                   (uint8_t *const *)c->d_later_masks.p, aa);
+            }
+        } else if (use_chain) {
             // :48-52 for keyframes [g0, g1) in one launch; order is kept by the in-kernel barrier
             ChainArgs ca;
             ca.f0 = (uint32_t)g0;
@@ -600,15 +629,16 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
                 AcceptArgs aa;
                 aa.c = ca;
                 const VerdictDev *vd = c->d_verdicts.p;
+                uint8_t *const *lm = c->d_later_masks.p;
                 aa.v_first = (uint32_t)a0;
                 aa.pad = 0;
                 hipEvent_t stop = c->profile ? nullptr : c->gev[g];
 #if SFM_STAMPS
                 if (stamp_this)
-                    hipExtLaunchKernelGGL(accept_chain_kernel_stamps, dim3(c->n_cu), dim3(kChainThreads), 0, sa, nullptr, stop, 0, fr, vd, aa);
+                    hipExtLaunchKernelGGL(accept_chain_kernel_stamps, dim3(c->n_cu), dim3(kChainThreads), 0, sa, nullptr, stop, 0, fr, vd, lm, aa);
                 else
 #endif
-                hipExtLaunchKernelGGL(accept_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), 0, sa, nullptr, stop, 0, fr, vd, aa);
+                hipExtLaunchKernelGGL(accept_chain_kernel, dim3(c->n_cu), dim3(kChainThreads), 0, sa, nullptr, stop, 0, fr, vd, lm, aa);
                 group_event_recorded = !c->profile;
             } else if (c->chain_coop) {
                 void *args[] = {(void *)&fr, (void *)&np, (void *)&ca};
@@ -643,7 +673,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             }
             if (c->profile) HIP_TRY(c, hipEventRecord(c->kev[4 * g + 1], sa));
         } else
-        for (size_t i = g0; i < g1; i++) {  // :48-52, strictly in order
+        for (size_t i = g0; i < g1 && !use_verdicts; i++) {  // :48-52, strictly in order
             const HostFrame &f = c->frames[i];
             const uint64_t px = (uint64_t)f.W * f.H;
             if (!px) continue;
@@ -874,7 +904,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
     release(c->d_rd_keys); release(c->d_rd_key3); release(c->d_rd_tag); release(c->d_rd_perm); release(c->d_rd_tmp);
     release(c->d_rd_xyz); release(c->d_rd_bgr);
-    release(c->d_mask_seed); release(c->d_verdict_arena); release(c->d_verdicts);
+    release(c->d_mask_seed); release(c->d_verdict_arena); release(c->d_verdicts); release(c->d_later_masks);
     release(c->d_part); release(c->d_gorder); release(c->d_tables); release(c->d_nbrpack); release(c->d_masks); release(c->d_table);
     release(c->d_list_key); release(c->d_list_tag); release(c->d_out_key);
     release(c->d_out_tag); release(c->d_cand); release(c->d_list_xyz); release(c->d_out_xyz);
@@ -1109,7 +1139,8 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     }
     if (c->layout_dirty && (rc = build_layout(c))) return rc;
     c->have_result = false;
-    if (c->auto_precompute && !c->have_verdicts && c->chain && (rc = sfm_fusion_precompute(c)) && rc != SFM_E_UNSUPPORTED) return rc;
+    // keyframes with more neighbours than the fused kernels hold always take the two-phase chain
+    if ((c->big_k || (c->auto_precompute && c->chain)) && !c->have_verdicts && (rc = sfm_fusion_precompute(c))) return rc;
     c->part_counts.clear();  // sfm_fusion_export_records needs counts of THIS run's cloud
     // a fallback is not for life: after kChainRetryRuns runs on the kernel pair the chain kernel is tried again
     // (three fallbacks in a ctx's life make it permanent: something else owns CUs of this device for good)
@@ -1245,8 +1276,6 @@ int sfm_fusion_precompute(sfm_fusion_ctx *c)
     for (size_t i = 0; i < n; i++)
         for (uint32_t j : c->frames[i].nbrs)
             if (j >= n || j == i) return fail(c, SFM_E_INVALID, "neighbour index out of range");
-    if (!c->chain || c->chain_items == 0)
-        return fail(c, SFM_E_UNSUPPORTED, "the two-phase chain needs the device-wide barrier this device or ctx does not have");
     const size_t a0 = std::min<size_t>(c->act_first, n), a1 = std::max(a0, std::min<size_t>(c->act_end, n));
     DevParams P;
     P.base_line = c->prm.base_line; P.T_cov = c->prm.T_cov; P.voxel_size = c->prm.voxel_size;
@@ -1256,33 +1285,41 @@ int sfm_fusion_precompute(sfm_fusion_ctx *c)
     bool shared = true;
     for (size_t i = 0; shared && i < n; i++)
         shared = chain_div_ok(P, c->frames[i].K, c->frames[i].W, c->frames[i].H, c->h_frames[i].Twk, c->h_frames[i].Tkw);
-    // arena: per active keyframe info u16[P] | rec 32 B [P] | hits u32 [n_later][P], each 256-byte aligned
+    // arena: per active keyframe info u32[P] | rec 32 B [P] | hits u32 [n_later][P], each 256-byte aligned
     auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
     std::vector<VerdictDev> hv(a1 - a0);
     std::vector<uint64_t> off(a1 - a0);
+    std::vector<uint8_t *> later;
     uint64_t total = 0;
     for (size_t i = a0; i < a1; i++) {
         const FrameDev &F = c->h_frames[i];
         VerdictDev &V = hv[i - a0];
         std::memset(&V, 0, sizeof V);
+        V.later_begin = (uint32_t)later.size();
         for (uint32_t k = 0; k < F.nbr_count; k++) {
             const uint32_t j = c->h_nbr[F.nbr_begin + k];
-            if (j > i) V.later_mask[V.n_later++] = c->h_frames[j].mask;
+            if (j > i) {
+                later.push_back(c->h_frames[j].mask);
+                V.n_later++;
+            }
         }
         const uint64_t px = (uint64_t)F.W * F.H;
         off[i - a0] = total;
-        total += up(px * 2) + up(px * sizeof(VerdictRec)) + up(px * 4 * V.n_later);
+        total += up(px * 4) + up(px * sizeof(VerdictRec)) + up(px * 4 * V.n_later);
     }
     if ((rc = ensure(c, c->d_verdict_arena, total))) return rc;
     if ((rc = ensure(c, c->d_verdicts, hv.size()))) return rc;
+    if ((rc = ensure(c, c->d_later_masks, later.size()))) return rc;
+    if (!later.empty())
+        HIP_TRY(c, hipMemcpy(c->d_later_masks.p, later.data(), later.size() * sizeof(uint8_t *), hipMemcpyHostToDevice));
     for (size_t i = a0; i < a1; i++) {
         const FrameDev &F = c->h_frames[i];
         VerdictDev &V = hv[i - a0];
         const uint64_t px = (uint64_t)F.W * F.H;
         unsigned char *p = c->d_verdict_arena.p + off[i - a0];
-        V.info = reinterpret_cast<uint16_t *>(p);
-        V.rec = reinterpret_cast<VerdictRec *>(p + up(px * 2));
-        V.hits = reinterpret_cast<uint32_t *>(p + up(px * 2) + up(px * sizeof(VerdictRec)));
+        V.info = reinterpret_cast<uint32_t *>(p);
+        V.rec = reinterpret_cast<VerdictRec *>(p + up(px * 4));
+        V.hits = reinterpret_cast<uint32_t *>(p + up(px * 4) + up(px * sizeof(VerdictRec)));
     }
     if (!hv.empty())
         HIP_TRY(c, hipMemcpy(c->d_verdicts.p, hv.data(), hv.size() * sizeof(VerdictDev), hipMemcpyHostToDevice));

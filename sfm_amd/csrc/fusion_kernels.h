@@ -39,7 +39,8 @@ namespace sfm {
 constexpr int kWave = 64;
 constexpr int kPxPerLane = 4;
 constexpr int kTile = kWave * kPxPerLane;  // 256 pixels per workgroup tile
-constexpr int kMaxK = 32;                  // SFM_MAX_NEIGHBORS
+constexpr int kMaxK = 32;                  // SFM_MAX_NEIGHBORS: filtered neighbours the fused kernels hold; more take the two-phase chain
+constexpr int kMaxKTwoPhase = 4095;        // ... whose per-pixel counters are 12 bits wide
 constexpr int kMaxWaves = 8;               // waves per workgroup of fuse_frame_kernel
 constexpr int kListShards = 16;            // append cursors (one 64-B line each)
 constexpr int kStatShards = 64;
@@ -1362,17 +1363,18 @@ struct VerdictRec {  // 32 bytes per pixel, valid where the verdict is positive
     double x, y, z;          // the fused point (:164), x86 NaN bits included
 };
 
-constexpr uint16_t kVOk = 0x8000u;        // geometric_check passed: the pixel yields a point if its mask is clear
-constexpr uint16_t kVKeyRange = 0x4000u;  // ... but its voxel index does not fit the packed key
-constexpr uint16_t kVCand = 0x2000u;      // depth > 0 and the covariance gate passed: the pixel reaches geometric_check
-// info = flags | kept observations << 6 | visible projections  (6 bits each: at most kMaxK = 32)
+constexpr uint32_t kVOk = 0x80000000u;        // geometric_check passed: the pixel yields a point if its mask is clear
+constexpr uint32_t kVKeyRange = 0x40000000u;  // ... but its voxel index does not fit the packed key
+constexpr uint32_t kVCand = 0x20000000u;      // depth > 0 and the covariance gate passed: the pixel reaches geometric_check
+// info = flags | kept observations << 12 | visible projections  (12 bits each: any number of neighbours up to 4095;
+// this path has no per-keyframe neighbour limit in LDS or registers -- a pixel's neighbours are a loop)
 
 struct VerdictDev {  // one per keyframe of the active range
-    uint16_t *info;        // [W*H]
+    uint32_t *info;        // [W*H]
     VerdictRec *rec;       // [W*H]
     uint32_t *hits;        // [n_later][W*H] pixel marked in the s-th LATER neighbour, kNoHit where nothing is kept
-    uint32_t n_later, pad;
-    uint8_t *later_mask[kMaxK];  // masks of the later neighbours, in neighbour order
+    uint32_t n_later;      // later neighbours of the keyframe ...
+    uint32_t later_begin;  // ... whose masks are later_masks[later_begin ...] (a kernel argument), in neighbour order
 };
 
 template <bool SHARED>
@@ -1438,13 +1440,13 @@ __global__ __launch_bounds__(256) void verdict_kernel(const FrameDev *__restrict
     }
     bool ok = cand && n_obs >= 1;                                        // :218
     if ((double)n_close < (double)n_obs * P.close_frac) ok = false;      // :229
-    uint16_t info = cand ? (uint16_t)(kVCand | (n_obs << 6) | n_vis) : (uint16_t)0;
+    uint32_t info = cand ? (kVCand | (n_obs << 12) | n_vis) : 0u;
     if (ok) {
         const double fx = x86_nan(wx / total), fy = x86_nan(wy / total), fz = x86_nan(wz / total);  // :164
         unsigned long long c0_, c1_, c2_;
         const int fits = (int)axis_code_of(fx, P.voxel_size, c0_) & (int)axis_code_of(fy, P.voxel_size, c1_) &
                          (int)axis_code_of(fz, P.voxel_size, c2_);
-        info |= fits ? kVOk : (uint16_t)(kVOk | kVKeyRange);
+        info |= fits ? kVOk : (kVOk | kVKeyRange);
         VerdictRec r;
         r.key = (c0_ << 42) | (c1_ << 21) | c2_;
         r.x = fx; r.y = fy; r.z = fz;
@@ -1472,7 +1474,8 @@ struct AcceptArgs {
 // were re-read by vector loads with a full vmcnt(0) wait in front of every prefetch load: 6 us per keyframe)
 template <bool STAMPS>
 __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ frames,
-                                                  const VerdictDev *__restrict__ verdicts, const AcceptArgs &aa)
+                                                  const VerdictDev *__restrict__ verdicts,
+                                                  uint8_t *const *__restrict__ later_masks, const AcceptArgs &aa)
 {
     static_assert(kAccIter * kChainWaves == kWave, "one wave scans the pass's per-wave counts");
     __shared__ unsigned int s_wave[kAccIter * kChainWaves], s_off[kAccIter * kChainWaves];
@@ -1488,6 +1491,7 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
     for (uint32_t f = a.f0; f < a.f1 && !aborted; f++) {
         const FrameDev &F = frames[f];
         const VerdictDev &V = verdicts[f - aa.v_first];
+        uint8_t *const *later_mask = later_masks + V.later_begin;
         const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
         SFM_CSTAMP(0);
         const uint32_t runs = F.nbr_count ? (npx + kWave - 1) / kWave : 0u;            // 64-pixel runs of the keyframe
@@ -1557,8 +1561,8 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
             for (int j = 0; j < kAccIter; j++) {
                 const bool live = (infov[j] & kVCand) && mv[j] == 0u;
                 acc[j] = live && (infov[j] & kVOk);
-                c_gather += live ? (infov[j] & 63u) : 0u;
-                c_hit += acc[j] ? ((infov[j] >> 6) & 63u) : 0u;
+                c_gather += live ? (infov[j] & 0xFFFu) : 0u;
+                c_hit += acc[j] ? ((infov[j] >> 12) & 0xFFFu) : 0u;
                 if (acc[j] && (infov[j] & kVKeyRange)) err |= kErrKeyRange;
                 const unsigned long long m = __ballot(acc[j]);
                 pos[j] = (unsigned)__popcll(m & lanemask_lt());
@@ -1570,7 +1574,7 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
             for (int j = 0; j < kAccIter; j++)
 #pragma unroll
                 for (int q = 0; q < 4; q++)
-                    if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit) mask_store_coherent(V.later_mask[q] + h[j][q]);
+                    if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit) mask_store_coherent(later_mask[q] + h[j][q]);
             // ... the others four at a time (unconditional loads: a lane without an accepted pixel reads element 0)
             for (uint32_t s0 = 4; s0 < nl; s0 += 4) {
                 uint32_t h2[kAccIter][4];
@@ -1584,7 +1588,7 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
 #pragma unroll
                     for (int q = 0; q < 4; q++)
                         if (acc[j] && s0 + (uint32_t)q < nl && h2[j][q] != kNoHit)
-                            mask_store_coherent(V.later_mask[s0 + q] + h2[j][q]);
+                            mask_store_coherent(later_mask[s0 + q] + h2[j][q]);
             }
             // the accepted pixels' fused points: requested now, so that their (cold, scattered) round trip runs under the
             // wait for the marks' acknowledgement instead of behind the barrier arrival (unconditional loads)
@@ -1651,7 +1655,9 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
             if (mine == 0) break;
         }
     }
-    if (threadIdx.x == 0) {  // list boundaries of the group, as in fuse_chain_kernel
+    // list boundaries of the group, as in fuse_chain_kernel (group == ~0: one launch per keyframe, no barrier words
+    // of its own; the host snapshots the cursors behind the group's last launch)
+    if (threadIdx.x == 0 && a.group != 0xFFFFFFFFu) {
         const unsigned left = __hip_atomic_fetch_add(a.bar + kBarDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (left == G - 1u) {
             unsigned long long *ge = a.list.group_end + (size_t)a.group * kListShards * 8;
@@ -1674,17 +1680,19 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
 }
 
 __global__ __launch_bounds__(kChainThreads) void accept_chain_kernel(const FrameDev *__restrict__ frames,
-                                                                     const VerdictDev *__restrict__ verdicts, AcceptArgs aa)
+                                                                     const VerdictDev *__restrict__ verdicts,
+                                                                     uint8_t *const *__restrict__ later_masks, AcceptArgs aa)
 {
-    accept_chain_body<false>(frames, verdicts, aa);
+    accept_chain_body<false>(frames, verdicts, later_masks, aa);
 }
 
 #if SFM_STAMPS
 __global__ __launch_bounds__(kChainThreads) void accept_chain_kernel_stamps(const FrameDev *__restrict__ frames,
                                                                             const VerdictDev *__restrict__ verdicts,
+                                                                            uint8_t *const *__restrict__ later_masks,
                                                                             AcceptArgs aa)
 {
-    accept_chain_body<true>(frames, verdicts, aa);
+    accept_chain_body<true>(frames, verdicts, later_masks, aa);
 }
 #endif
 

@@ -30,7 +30,8 @@ def run_gpu(frames, gparams, device=0):
     want_path = os.environ.get("SFM_FUSE_CHAIN")
     if want_path is not None and len(frames):
         assert st["fused_chain"] == int(want_path != "0"), "the other keyframe-chain path ran"
-        if st["fused_chain"]:
+        many = any(len(f.get("nbrs", [])) > fusion.SFM_MAX_NEIGHBORS for f in frames)   # those always run two-phase
+        if st["fused_chain"] and not many:
             assert st["precomputed"] == int(os.environ.get("SFM_PRECOMPUTE", "0") == "1"), "one-phase / two-phase chain mix-up"
     return dict(xyz=xyz, bgr=bgr, key=key, tag=tag, stats=st, frame_before=fb, frame_after=fa)
 

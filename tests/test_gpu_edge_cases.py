@@ -157,13 +157,36 @@ def test_argument_errors():
     with pytest.raises(fusion.FusionError):
         ctx.run()                              # unknown neighbour
     ctx.close()
+
+
+def test_more_neighbours_than_the_fused_kernels_hold():
+    """The reference has no neighbour cap (map.cpp:152-160).  39 and 71 mutual neighbours per keyframe: more than
+    SFM_MAX_NEIGHBORS, so the run takes the two-phase chain (a pixel's neighbours are a loop there) on every path."""
     far = []
     for i in range(40):
         far.append(scenes.frame(np.full((4, 4), 30), K=(5, 5, 1.5, 1.5), C=(0.1 * i, 0, 0),
                                 nbrs=[j for j in range(40) if j != i]))
-    with pytest.raises(fusion.FusionError) as e:
-        run_gpu(far, fusion.default_params())
-    assert e.value.code == fusion.SFM_E_UNSUPPORTED   # > SFM_MAX_NEIGHBORS filtered neighbours
+    op, gp = both_params()
+    g = run_gpu(far, gp)
+    assert g["stats"]["precomputed"] == 1
+    assert_same_cloud(g, oracle.fuse(far, op))
+    seq = synth.make_sequence(72, 64, 48, K=(131.25, 131.25, 31.5, 23.5), window=71, yaw_step_deg=0.5)
+    frames = seq.frame_dicts()
+    assert min(len(f["nbrs"]) for f in frames) == 71
+    op, gp = both_params(voxel_size=20.0, T_dist=500.0)
+    want = oracle.fuse(frames, op, n_threads=8)
+    assert want.key.shape[0] > 1000 and want.counters["n_hit"] > 10 * want.counters["n_acc"]
+    g = run_gpu(frames, gp)
+    assert g["stats"]["precomputed"] == 1
+    assert_same_cloud(g, want)
+    # 33 neighbours on ONE keyframe only is enough to switch the run over; 32 is not
+    seq = synth.make_sequence(40, 48, 36, K=(98.4, 98.4, 23.5, 17.5), window=2, yaw_step_deg=0.5)
+    frames = seq.frame_dicts()
+    frames[3]["nbrs"] = [j for j in range(34) if j != 3]
+    assert_same_cloud(run_gpu(frames, gp), oracle.fuse(frames, op))
+    frames[3]["nbrs"] = [j for j in range(33) if j != 3]
+    g = run_gpu(frames, gp)
+    assert_same_cloud(g, oracle.fuse(frames, op))
 
 
 def _run_raw(frames, gp):
@@ -180,9 +203,11 @@ def _run_raw(frames, gp):
     return dict(xyz=xyz, bgr=bgr, key=key, tag=tag, stats=st, frame_before=fb, frame_after=fa)
 
 
-def test_division_operands_outside_the_shared_range_fall_back_to_plain_division():
+def test_division_operands_outside_the_shared_range_fall_back_to_plain_division(fusion_path):
     """fuse_chain_kernel divides in pairs with a shared reciprocal, exact for operands within
-    [2^-400, 2^400]; anything else must end on the kernel pair (plain divisions), never in a wrong bit."""
+    [2^-400, 2^400]; anything else must end on the kernel pair (plain divisions), never in a wrong bit.  (The
+    two-phase chain picks verdict_kernel's plain-division instantiation instead and keeps the barrier chain.)"""
+    two_phase = fusion_path == "verdict"
     frames = scenes.plane_pair()
     for f in frames:
         f["T_kw"] = f["T_kw"] * 2.0 ** -500          # camera coordinates of ~2^-495: same projections, exactly
@@ -190,13 +215,14 @@ def test_division_operands_outside_the_shared_range_fall_back_to_plain_division(
     want = oracle.fuse(frames, op)
     assert want.key.shape[0] > 100
     g = _run_raw(frames, gp)
-    assert g["stats"]["fused_chain"] == 0            # flagged in the kernel (kErrDivRange), rerun on the pair
+    assert g["stats"]["fused_chain"] == int(two_phase)   # refused on the host (chain_div_ok): the pair runs
+    assert g["stats"]["precomputed"] == int(two_phase)
     assert_same_cloud(g, want)
     frames = scenes.plane_pair()
     op, gp = both_params(base_line=2.0 ** -450)      # disparity^2 ~ 2^-890: refused on the host before the launch
     want = oracle.fuse(frames, op)
     g = _run_raw(frames, gp)
-    assert g["stats"]["fused_chain"] == 0
+    assert g["stats"]["fused_chain"] == int(two_phase)
     assert_same_cloud(g, want)
 
 
