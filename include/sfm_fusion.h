@@ -33,7 +33,7 @@ extern "C" {
 #define SFM_E_INVALID (-1)     /* bad argument / bad call order */
 #define SFM_E_HIP (-2)         /* HIP runtime error (text in last_error) */
 #define SFM_E_TABLE_FULL (-3)  /* voxel table capacity exhausted */
-#define SFM_E_KEY_RANGE (-4)   /* a voxel index does not fit the packed 3x21-bit key */
+#define SFM_E_KEY_RANGE (-4)   /* the cloud's voxel indices need more than 63 bits in all (see sfm_fusion_get_key_range) */
 #define SFM_E_CAPACITY (-5)    /* accepted-point list capacity exhausted */
 #define SFM_E_UNSUPPORTED (-6) /* e.g. more than 4095 filtered neighbours of one keyframe */
 #define SFM_E_NOMEM (-7)
@@ -180,7 +180,19 @@ int sfm_fusion_get_frame_counts(sfm_fusion_ctx *ctx, uint64_t *before, uint64_t 
 /* Global processing order of each of this ctx's keyframes (strictly increasing, one entry per
  * keyframe).  Exported records and sfm_fusion_read_points tags then carry global orders. */
 int sfm_fusion_set_global_order(sfm_fusion_ctx *ctx, const uint32_t *order, uint32_t n);
-/* After sfm_fusion_run: how many local winners each of n_parts owners gets. */
+/* The voxel key -- three size_t in the reference (:270-274) -- travels inside the library as ONE exact 64-bit word:
+ * per axis the code of an index within a range [lo, hi] (or of x86's "indefinite" index), +-(2^20 - 1) and 21 bits
+ * each by default.  A run with voxel indices outside the ranges (a cloud far from the origin, a very large one)
+ * notices, scans the index range of its fused points in a second pass and runs a third time with exactly those
+ * ranges; later runs of the ctx start with them.  Exact while the three code widths sum to <= 63 bits
+ * (SFM_E_KEY_RANGE beyond: a cloud spanning more than 2^21 voxels in every one of the three axes at once).
+ * sfm_fusion_read_points always returns the full three size_t.  Ranks that exchange records must pack alike:
+ * the exchange takes the hull of all ranks' get_key_range and sets it everywhere (set_key_range re-encodes the
+ * cloud at hand and fails, changing nothing, if that cloud has an index outside the new ranges). */
+int sfm_fusion_get_key_range(sfm_fusion_ctx *ctx, int64_t lo[3], int64_t hi[3]);
+int sfm_fusion_set_key_range(sfm_fusion_ctx *ctx, const int64_t lo[3], const int64_t hi[3]);
+/* After sfm_fusion_run: how many local winners each of n_parts owners gets (the owner is a hash of the three voxel
+ * indices, independent of the packing). */
 int sfm_fusion_partition_counts(sfm_fusion_ctx *ctx, uint32_t n_parts, uint64_t *counts);
 /* sfm_fusion_partition_counts for callers that cannot allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result; the kernel's per-owner

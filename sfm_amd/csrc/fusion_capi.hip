@@ -69,6 +69,9 @@ struct HostCounters {  // pinned snapshot read back after the frame loop
     Counters ctr;
     alignas(64) unsigned long long cursor[kListShards * 8];
     alignas(64) StatShard stat[kStatShards];
+    // range-scan run: index range of every fused point, per shard.  Last, and outside the per-run memset: a two-phase
+    // run fills it in sfm_fusion_precompute, before sfm_fusion_run's own launches
+    alignas(64) KeyRangeDev key_scan[kStatShards];
 };
 
 }  // namespace
@@ -176,6 +179,10 @@ struct sfm_fusion_ctx {
     // One sequence over several GPUs (sfm_fusion_set_active_range): only keyframes [act_first, act_end) are fused
     // by this ctx, the others lend images and poses and hold masks.  mask_seed = the visibility masks the run
     // starts from (what the ranks before this one left, sfm_fusion_import_masks) instead of zeros.
+    // the exact key packing in use (DevParams::key): voxel indices held per axis, and the code widths that follow
+    KeyRangeDev key = {{-1048575, -1048575, -1048575}, {1048575, 1048575, 1048575}};
+    uint32_t key_bits[3] = {21, 21, 21};
+    bool key_scan = false;             // the attempt at hand is a range-scan run
     uint32_t act_first = 0, act_end = 0xFFFFFFFFu;
     std::vector<uint64_t> mask_off;    // per keyframe: offset of its mask in d_masks
     DevBuf<uint8_t> d_mask_seed;
@@ -201,8 +208,49 @@ struct sfm_fusion_ctx {
 namespace {
 
 constexpr size_t kSmallBytes = sizeof(HostCounters);
+constexpr size_t kSmallZeroBytes = offsetof(HostCounters, key_scan);  // what every run zeroes
 
 Counters *dev_ctr(sfm_fusion_ctx *c) { return reinterpret_cast<Counters *>(c->d_small); }
+KeyRangeDev *dev_key_scan(sfm_fusion_ctx *c)
+{
+    return reinterpret_cast<KeyRangeDev *>(c->d_small + offsetof(HostCounters, key_scan));
+}
+uint32_t bits_for_range(long long lo, long long hi)
+{
+    const unsigned long long codes = axis_code_count(lo, hi);
+    uint32_t b = 1;
+    while (b < 64 && (1ull << b) < codes) b++;
+    return b;
+}
+bool key_is_default(const KeyRangeDev &k)
+{
+    for (int a = 0; a < 3; a++)
+        if (k.lo[a] != -1048575 || k.hi[a] != 1048575) return false;
+    return true;
+}
+KeyPack key_pack_of(const KeyRangeDev &k)
+{
+    KeyPack kp;
+    for (int a = 0; a < 3; a++) {
+        kp.lo[a] = k.lo[a];
+        kp.hi[a] = k.hi[a];
+        kp.b[a] = bits_for_range(k.lo[a], k.hi[a]);
+    }
+    return kp;
+}
+KeyPack key_bits_of(const sfm_fusion_ctx *c) { return key_pack_of(c->key); }
+// 0 when the ranges make an exact 64-bit key, else why not
+const char *key_range_problem(const long long lo[3], const long long hi[3])
+{
+    uint32_t sum = 0;
+    for (int a = 0; a < 3; a++) {
+        if (lo[a] > hi[a]) return "empty index range";
+        if (lo[a] < -(1ll << 62) || hi[a] > (1ll << 62) || (unsigned long long)(hi[a] - lo[a]) >= (1ull << 53))
+            return "index range of an axis wider than 2^53";
+        sum += bits_for_range(lo[a], hi[a]);
+    }
+    return sum > 63 ? "the three axes need more than 63 bits in all" : nullptr;
+}
 unsigned long long *dev_cursor(sfm_fusion_ctx *c)
 {
     return reinterpret_cast<unsigned long long *>(c->d_small + offsetof(HostCounters, cursor));
@@ -322,6 +370,43 @@ void rows3(const double cm[16], double out[12])
         for (int col = 0; col < 4; col++) out[r * 4 + col] = cm[r + 4 * col];
 }
 
+double sqrt_threshold(double T);
+
+int reset_key_scan(sfm_fusion_ctx *c)
+{
+    static const std::vector<KeyRangeDev> empty = [] {
+        std::vector<KeyRangeDev> v(kStatShards);
+        for (auto &r : v)
+            for (int ax = 0; ax < 3; ax++) {
+                r.lo[ax] = std::numeric_limits<long long>::max();
+                r.hi[ax] = std::numeric_limits<long long>::min();
+            }
+        return v;
+    }();
+    HIP_TRY(c, hipMemcpyAsync(dev_key_scan(c), empty.data(), sizeof(KeyRangeDev) * kStatShards, hipMemcpyHostToDevice, c->stream));
+    return SFM_OK;
+}
+
+DevParams make_dev_params(sfm_fusion_ctx *c)
+{
+    DevParams P;
+    P.base_line = c->prm.base_line;
+    P.T_cov = c->prm.T_cov;
+    P.voxel_size = c->prm.voxel_size;
+    P.tau_dist2 = sqrt_threshold(c->prm.T_dist);
+    P.S0 = c->prm.S[0];
+    P.S1 = c->prm.S[1];
+    P.S2 = c->prm.S[2];
+    P.depth_div = c->prm.depth_div;
+    P.close_frac = c->prm.close_frac;
+    P.key = c->key;
+    for (int a = 0; a < 3; a++) P.key_bits[a] = c->key_bits[a];
+    P.key_wide = key_is_default(c->key) ? 0u : 1u;
+    P.key_scan = c->key_scan ? 1u : 0u;
+    P.key_scan_out = dev_key_scan(c);
+    return P;
+}
+
 int build_layout(sfm_fusion_ctx *c)
 {
     const size_t n = c->frames.size();
@@ -385,10 +470,7 @@ int build_layout(sfm_fusion_ctx *c)
     }
     if ((rc = ensure(c, c->d_tables, tab_doubles))) return rc;
     {
-        DevParams P;
-        P.base_line = c->prm.base_line; P.T_cov = c->prm.T_cov; P.voxel_size = c->prm.voxel_size;
-        P.tau_dist2 = 0; P.S0 = c->prm.S[0]; P.S1 = c->prm.S[1]; P.S2 = c->prm.S[2];
-        P.depth_div = c->prm.depth_div; P.close_frac = c->prm.close_frac;
+        const DevParams P = make_dev_params(c);
         for (auto &e : covs)
             hipLaunchKernelGGL(build_cov_table, dim3(256), dim3(256), 0, c->stream, c->d_tables.p + e.second, e.first, P);
         for (auto &a : axes)
@@ -494,7 +576,9 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
         HIP_TRY(c, hipMemsetAsync(c->d_masks.p, 0, c->d_masks.n, sa));  // :40-45
     // the table is first touched by the first group's table kernel: its fill runs on stream B, under the first chain launch
     HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0xFF, table_cap * sizeof(Slot), sb));
-    HIP_TRY(c, hipMemsetAsync(c->d_small, 0, kSmallBytes, sa));
+    HIP_TRY(c, hipMemsetAsync(c->d_small, 0, kSmallZeroBytes, sa));
+    // a range-scan run starts from empty ranges (a two-phase one has scanned in sfm_fusion_precompute already)
+    if (c->key_scan && !c->have_verdicts && (rc = reset_key_scan(c))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_zero.p, 0, c->z_bytes, sa));  // counts, barrier words, queue cursors
     HIP_TRY(c, hipEventRecord(c->ev_init, sa));
     HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_init, 0));
@@ -516,15 +600,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     FuseArgs a;
     a.list = list;
     a.stat = dev_stat(c);
-    a.P.base_line = c->prm.base_line;
-    a.P.T_cov = c->prm.T_cov;
-    a.P.voxel_size = c->prm.voxel_size;
-    a.P.tau_dist2 = sqrt_threshold(c->prm.T_dist);
-    a.P.S0 = c->prm.S[0];
-    a.P.S1 = c->prm.S[1];
-    a.P.S2 = c->prm.S[2];
-    a.P.depth_div = c->prm.depth_div;
-    a.P.close_frac = c->prm.close_frac;
+    a.P = make_dev_params(c);
 
     TableArgs t;
     t.table = c->d_table.p;
@@ -1158,6 +1234,8 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     // 5-mm C5 sample one per 21); the exact need is known after an overflowing run
     uint64_t out_cap = std::max<uint64_t>(c->out_cap, std::max<uint64_t>(c->total_px / 16, 1 << 12));
     const uint64_t shard_max = c->total_px + kTile;  // every pixel live, all tiles in one shard
+    int key_attempts = 0;
+    c->key_scan = false;
     for (int attempt = 0;; attempt++) {
         uint32_t err = 0;
         if ((rc = run_once(c, table_cap, shard_cap, out_cap, &err))) return rc;
@@ -1175,9 +1253,38 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
             c->chain_off_runs = 8;
             continue;
         }
-        if (err & kErrKeyRange)
-            return fail(c, SFM_E_KEY_RANGE,
-                        "a fused point's voxel index is outside the packed key range of +-(2^20-1) per axis");
+        if (err & kErrKeyRange) {
+            // Some voxel index does not fit the key packing.  Next attempt: a range-scan run (no records, every fused
+            // point leaves its indices); the one after packs with exactly the ranges found.  The packing is exact while
+            // the three code widths sum to <= 63 bits.
+            if (!c->key_scan) {
+                if (key_attempts++ >= 2) return fail(c, SFM_E_KEY_RANGE, "voxel indices outside the ranges a scan found");
+                c->key_scan = true;
+            } else {
+                c->key_scan = false;
+                KeyRangeDev r = c->h_small->key_scan[0];
+                for (int sh = 1; sh < kStatShards; sh++)
+                    for (int ax = 0; ax < 3; ax++) {
+                        r.lo[ax] = std::min(r.lo[ax], c->h_small->key_scan[sh].lo[ax]);
+                        r.hi[ax] = std::max(r.hi[ax], c->h_small->key_scan[sh].hi[ax]);
+                    }
+                for (int ax = 0; ax < 3; ax++)
+                    if (r.lo[ax] > r.hi[ax]) r.lo[ax] = r.hi[ax] = 0;  // only indefinite indices on this axis
+                if (const char *why = key_range_problem(r.lo, r.hi))
+                    return fail(c, SFM_E_KEY_RANGE, std::string("no exact 64-bit voxel key for this cloud: ") + why);
+                c->key = r;
+                for (int ax = 0; ax < 3; ax++) c->key_bits[ax] = bits_for_range(r.lo[ax], r.hi[ax]);
+            }
+            if (c->have_verdicts) {  // their records hold keys of the old packing
+                c->have_verdicts = false;
+                if ((rc = sfm_fusion_precompute(c))) return rc;
+            }
+            continue;
+        }
+        if (c->key_scan) {  // a scan run that found nothing unfit cannot happen; never leave the mode on
+            c->key_scan = false;
+            return fail(c, SFM_E_KEY_RANGE, "range scan ended without a range");
+        }
         bool grown = false;
         if (err & kErrOutFull) {
             const uint64_t need = c->h_small->ctr.out_count;  // the counter kept counting
@@ -1277,10 +1384,7 @@ int sfm_fusion_precompute(sfm_fusion_ctx *c)
         for (uint32_t j : c->frames[i].nbrs)
             if (j >= n || j == i) return fail(c, SFM_E_INVALID, "neighbour index out of range");
     const size_t a0 = std::min<size_t>(c->act_first, n), a1 = std::max(a0, std::min<size_t>(c->act_end, n));
-    DevParams P;
-    P.base_line = c->prm.base_line; P.T_cov = c->prm.T_cov; P.voxel_size = c->prm.voxel_size;
-    P.tau_dist2 = sqrt_threshold(c->prm.T_dist); P.S0 = c->prm.S[0]; P.S1 = c->prm.S[1]; P.S2 = c->prm.S[2];
-    P.depth_div = c->prm.depth_div; P.close_frac = c->prm.close_frac;
+    const DevParams P = make_dev_params(c);
     // the shared-reciprocal divisions need operands in their range, for the keyframe and for its neighbours
     bool shared = true;
     for (size_t i = 0; shared && i < n; i++)
@@ -1323,6 +1427,7 @@ int sfm_fusion_precompute(sfm_fusion_ctx *c)
     }
     if (!hv.empty())
         HIP_TRY(c, hipMemcpy(c->d_verdicts.p, hv.data(), hv.size() * sizeof(VerdictDev), hipMemcpyHostToDevice));
+    if (c->key_scan && (rc = reset_key_scan(c))) return rc;  // the scan of a two-phase run happens here
     // phase A: no order between keyframes; one launch per 32 keyframes keeps the grids moderate
     HIP_TRY(c, hipEventRecord(c->ev_pa[0], c->stream));
     for (size_t g0 = a0; g0 < a1; g0 += kGroup) {
@@ -1443,6 +1548,51 @@ int sfm_fusion_set_global_order(sfm_fusion_ctx *c, const uint32_t *order, uint32
     return SFM_OK;
 }
 
+int sfm_fusion_get_key_range(sfm_fusion_ctx *c, int64_t lo[3], int64_t hi[3])
+{
+    if (!c || !lo || !hi) return SFM_E_INVALID;
+    for (int a = 0; a < 3; a++) {
+        lo[a] = c->key.lo[a];
+        hi[a] = c->key.hi[a];
+    }
+    return SFM_OK;
+}
+
+int sfm_fusion_set_key_range(sfm_fusion_ctx *c, const int64_t lo[3], const int64_t hi[3])
+{
+    if (!c || !lo || !hi) return SFM_E_INVALID;
+    KeyRangeDev nk;
+    for (int a = 0; a < 3; a++) {
+        nk.lo[a] = lo[a];
+        nk.hi[a] = hi[a];
+    }
+    if (const char *why = key_range_problem(nk.lo, nk.hi)) return fail(c, SFM_E_KEY_RANGE, std::string("key range: ") + why);
+    if (std::memcmp(&nk, &c->key, sizeof nk) == 0) return SFM_OK;
+    if (c->have_result && c->n_out) {  // the cloud at hand keeps its voxels: re-encode its keys
+        HIP_TRY(c, hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        int rc;
+        if ((rc = ensure(c, c->d_rd_keys, c->n_out))) return rc;  // (scratch of sfm_fusion_read_points)
+        HIP_TRY(c, hipMemsetAsync(c->d_small, 0, sizeof(Counters), s));
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((c->n_out + 255) / 256, 4096);
+        hipLaunchKernelGGL(rekey_kernel, dim3(blocks), dim3(256), 0, s, (const unsigned long long *)c->d_out_key.p,
+                           c->d_rd_keys.p, (unsigned long long)c->n_out, key_bits_of(c), key_pack_of(nk), dev_ctr(c));
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(&c->h_small->ctr, c->d_small, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (c->h_small->ctr.err)  // the new ranges do not hold this cloud: nothing was changed
+            return fail(c, SFM_E_KEY_RANGE, "the cloud at hand has voxel indices outside the requested ranges");
+        HIP_TRY(c, hipMemcpyAsync(c->d_out_key.p, c->d_rd_keys.p, c->n_out * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        c->part_counts.clear();
+    }
+    c->key = nk;
+    for (int a = 0; a < 3; a++) c->key_bits[a] = bits_for_range(nk.lo[a], nk.hi[a]);
+    c->have_verdicts = false;  // their records hold packed keys
+    return SFM_OK;
+}
+
 int sfm_fusion_partition_counts(sfm_fusion_ctx *c, uint32_t n_parts, uint64_t *counts)
 {
     if (!c || !counts || n_parts == 0 || n_parts > 1024) return fail(c, SFM_E_INVALID, "bad partition argument");
@@ -1455,7 +1605,7 @@ int sfm_fusion_partition_counts(sfm_fusion_ctx *c, uint32_t n_parts, uint64_t *c
     if (c->n_out) {
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((c->n_out + 255) / 256, 1024);
         hipLaunchKernelGGL(partition_count_kernel, dim3(blocks), dim3(256), 0, s, c->d_out_key.p,
-                           (unsigned long long)c->n_out, n_parts, c->d_part.p);
+                           (unsigned long long)c->n_out, n_parts, key_bits_of(c), c->d_part.p);
         HIP_TRY(c, hipGetLastError());
     }
     c->part_counts.assign(n_parts, 0);
@@ -1482,7 +1632,7 @@ int sfm_fusion_partition_counts_noalloc(sfm_fusion_ctx *c, uint32_t n_parts, uin
     if (c->n_out) {
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((c->n_out + 255) / 256, 1024);
         hipLaunchKernelGGL(partition_count_kernel, dim3(blocks), dim3(256), 0, s, c->d_out_key.p,
-                           (unsigned long long)c->n_out, n_parts, ptr);
+                           (unsigned long long)c->n_out, n_parts, key_bits_of(c), ptr);
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_part, ptr, (size_t)n_parts * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -1516,7 +1666,7 @@ int sfm_fusion_export_records(sfm_fusion_ctx *c, void *dst_dev, uint64_t dst_byt
     if (c->n_out) {
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((c->n_out + 255) / 256, 2048);
         hipLaunchKernelGGL(partition_scatter_kernel, dim3(blocks), dim3(256), 0, s, c->d_out_key.p, c->d_out_tag.p,
-                           c->d_out_xyz.p, c->d_out_bgr.p, (unsigned long long)c->n_out, n_parts,
+                           c->d_out_xyz.p, c->d_out_bgr.p, (unsigned long long)c->n_out, n_parts, key_bits_of(c),
                            (const uint32_t *)c->d_gorder.p, c->d_part.p + n_parts, (Record *)dst_dev);
         HIP_TRY(c, hipGetLastError());
     }
@@ -1603,8 +1753,8 @@ int sfm_fusion_read_points(sfm_fusion_ctx *c, double *xyz, int32_t *bgr, uint64_
                        (unsigned long long)n, (const unsigned long long *)c->d_out_key.p,
                        (const unsigned long long *)c->d_out_tag.p, (const double *)c->d_out_xyz.p,
                        (const uint32_t *)c->d_out_bgr.p, (const uint32_t *)c->d_gorder.p,
-                       remap ? (uint32_t)c->global_order.size() : 0u, c->d_rd_xyz.p, c->d_rd_bgr.p, c->d_rd_key3.p,
-                       c->d_rd_tag.p);
+                       remap ? (uint32_t)c->global_order.size() : 0u, key_bits_of(c), c->d_rd_xyz.p, c->d_rd_bgr.p,
+                       c->d_rd_key3.p, c->d_rd_tag.p);
     HIP_TRY(c, hipGetLastError());
     if (xyz) HIP_TRY(c, hipMemcpyAsync(xyz, c->d_rd_xyz.p, n * 24, hipMemcpyDeviceToHost, s));
     if (bgr) HIP_TRY(c, hipMemcpyAsync(bgr, c->d_rd_bgr.p, n * 12, hipMemcpyDeviceToHost, s));

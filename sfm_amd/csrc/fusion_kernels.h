@@ -72,10 +72,27 @@ struct FrameDev {
     uint32_t order, pad;
 };
 
+// Per axis, the voxel indices a run's key packing holds: [lo, hi] plus x86's "indefinite" index.  Also what a
+// range-scan run reports: the smallest and largest index of any fused point (kStatShards copies, combined on the host).
+struct KeyRangeDev {
+    long long lo[3], hi[3];
+};
+
 struct DevParams {
     double base_line, T_cov, voxel_size;
     double tau_dist2;  // smallest s with sqrt(s) >= T_dist: "norm < T_dist"  <=>  s < tau_dist2
     double S0, S1, S2, depth_div, close_frac;
+    // The voxel key (three size_t, :270-274) packed EXACTLY into one 64-bit word.  Per axis a code of key_bits[a] bits:
+    //   index in [max(lo,0), hi] -> index - max(lo,0);  the indefinite index -> n_nonneg;  index in [lo, -1] -> n_nonneg
+    //   + 1 + (index - lo)   -- ascending codes = ascending unsigned size_t, so that sorting packed keys sorts the
+    // reference's tuples.  Default: lo = -(2^20-1), hi = 2^20-1, 21 bits, i.e. plain two's complement with 0x100000 for
+    // the indefinite index (key_wide == 0: 32-bit conversions only).  A run whose indices do not fit is followed by a
+    // range-scan run (key_scan) and a run with the ranges it found; exact while the widths sum to <= 63 bits.
+    KeyRangeDev key;
+    uint32_t key_bits[3];
+    uint32_t key_wide;       // not the default packing: indices go through 64-bit conversions
+    uint32_t key_scan;       // range-scan run: record every fused point's indices in key_scan_out, emit no records
+    KeyRangeDev *key_scan_out;  // [kStatShards]
 };
 
 struct Slot {  // 32 bytes: everything an insert touches sits in one 64-byte sector
@@ -235,17 +252,9 @@ __device__ __forceinline__ long long voxel_index(double coord, double vs)
     return INT64_MIN;
 }
 
-// 21-bit two's-complement code per axis; -2^20 is reserved for INT64_MIN.
-__device__ __forceinline__ bool axis_code(long long k, unsigned long long &code)
-{
-    if (k == INT64_MIN) { code = 0x100000ull; return true; }
-    if (k < -1048575ll || k > 1048575ll) return false;
-    code = (unsigned long long)k & 0x1FFFFFull;
-    return true;
-}
-
-// axis_code(voxel_index(coord, vs)) without 64-bit conversions: the packed key only holds indices
-// within +-(2^20 - 1) and the indefinite value (NaN, >= 2^64, <= -2^63 -- voxel_index's INT64_MIN cases).
+// Default packing: 21-bit two's-complement code of static_cast<size_t>(coord / vs); 0x100000 is reserved for the
+// indefinite index (NaN, >= 2^64, <= -2^63 -- voxel_index's INT64_MIN cases).  32-bit conversions only.
+// Returns false when the index does not fit.
 __device__ __forceinline__ bool axis_code_of(double coord, double vs, unsigned long long &code)
 {
     const double q = coord / vs;
@@ -258,6 +267,63 @@ __device__ __forceinline__ bool axis_code_of(double coord, double vs, unsigned l
     }
     code = 0x100000ull;
     return (q != q) || t >= 18446744073709551616.0 || t <= -9223372036854775808.0;
+}
+
+// General packing (DevParams::key): code of index k (INT64_MIN = indefinite) within [lo, hi]
+__host__ __device__ inline bool axis_code_range(long long k, long long lo, long long hi, unsigned long long &code)
+{
+    const long long nn0 = lo > 0 ? lo : 0;                                   // first non-negative index held
+    const unsigned long long n_nonneg = hi >= 0 ? (unsigned long long)(hi - nn0) + 1ull : 0ull;
+    if (k == INT64_MIN) { code = n_nonneg; return true; }
+    if (k < lo || k > hi) { code = n_nonneg; return false; }
+    code = k >= 0 ? (unsigned long long)(k - nn0) : n_nonneg + 1ull + (unsigned long long)(k - lo);
+    return true;
+}
+
+// ... and back to the reference's size_t key component
+__host__ __device__ inline unsigned long long axis_decode_range(unsigned long long code, long long lo, long long hi)
+{
+    const long long nn0 = lo > 0 ? lo : 0;
+    const unsigned long long n_nonneg = hi >= 0 ? (unsigned long long)(hi - nn0) + 1ull : 0ull;
+    if (code < n_nonneg) return (unsigned long long)(nn0 + (long long)code);
+    if (code == n_nonneg) return 0x8000000000000000ull;
+    return (unsigned long long)(lo + (long long)(code - n_nonneg - 1ull));
+}
+
+// codes an axis [lo, hi] needs: its indices and the indefinite one
+__host__ __device__ inline unsigned long long axis_code_count(long long lo, long long hi)
+{
+    return (unsigned long long)(hi - lo) + 2ull;  // (lo <= hi; callers keep hi - lo < 2^53)
+}
+
+// The packed key of a fused point.  false: an index does not fit the run's packing (the caller raises kErrKeyRange),
+// or this is a range-scan run (every point is "unfit" and leaves its indices in key_scan_out).
+__device__ __forceinline__ bool pack_voxel_key(const DevParams &P, double fx, double fy, double fz, unsigned long long &key)
+{
+    unsigned long long c0, c1, c2;
+    if (!P.key_wide && !P.key_scan) {  // wave-uniform
+        const int fits = (int)axis_code_of(fx, P.voxel_size, c0) & (int)axis_code_of(fy, P.voxel_size, c1) &
+                         (int)axis_code_of(fz, P.voxel_size, c2);
+        key = (c0 << 42) | (c1 << 21) | c2;
+        return fits != 0;
+    }
+    const long long i0 = voxel_index(fx, P.voxel_size), i1 = voxel_index(fy, P.voxel_size), i2 = voxel_index(fz, P.voxel_size);
+    if (P.key_scan) {
+        KeyRangeDev *r = P.key_scan_out + (blockIdx.x + threadIdx.x / 64u) % kStatShards;
+        const long long v[3] = {i0, i1, i2};
+        for (int a = 0; a < 3; a++) {
+            if (v[a] == INT64_MIN) continue;
+            // (the plain reads may be stale: then an atomic too many is issued, never one too few)
+            if (v[a] < r->lo[a]) __hip_atomic_fetch_min(&r->lo[a], v[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v[a] > r->hi[a]) __hip_atomic_fetch_max(&r->hi[a], v[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        key = 0;
+        return false;
+    }
+    const int fits = (int)axis_code_range(i0, P.key.lo[0], P.key.hi[0], c0) & (int)axis_code_range(i1, P.key.lo[1], P.key.hi[1], c1) &
+                     (int)axis_code_range(i2, P.key.lo[2], P.key.hi[2], c2);
+    key = (c0 << (P.key_bits[1] + P.key_bits[2])) | (c1 << P.key_bits[2]) | c2;
+    return fits != 0;
 }
 
 // Every NaN the reference can produce on this path is x86's "real indefinite" (sign bit set, quiet,
@@ -667,11 +733,7 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
             double fx = 0, fy = 0, fz = 0;
             if (ok) {
                 fx = x86_nan(wx / total); fy = x86_nan(wy / total); fz = x86_nan(wz / total);           // :164
-                unsigned long long c0_, c1_, c2_;
-                const int fits = (int)axis_code_of(fx, P.voxel_size, c0_) & (int)axis_code_of(fy, P.voxel_size, c1_) &
-                                 (int)axis_code_of(fz, P.voxel_size, c2_);
-                if (fits) {
-                    key = (c0_ << 42) | (c1_ << 21) | c2_;
+                if (pack_voxel_key(P, fx, fy, fz, key)) {
                     tag = ((unsigned long long)F.order << 32) | pix;
                 } else {
                     atomicOr(&a.stat[blockIdx.x % kStatShards].err, kErrKeyRange);
@@ -1238,12 +1300,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                         double fx = 0, fy = 0, fz = 0;
                         if (ok) {
                             fx = x86_nan(wx / total); fy = x86_nan(wy / total); fz = x86_nan(wz / total);               // :164
-                            unsigned long long c0_, c1_, c2_;
-                            const int fits = (int)axis_code_of(fx, P.voxel_size, c0_) &
-                                             (int)axis_code_of(fy, P.voxel_size, c1_) &
-                                             (int)axis_code_of(fz, P.voxel_size, c2_);
-                            if (fits) {
-                                key = (c0_ << 42) | (c1_ << 21) | c2_;
+                            if (pack_voxel_key(P, fx, fy, fz, key)) {
                                 tag = ((unsigned long long)F.order << 32) | pixf;
                             } else {
                                 err |= kErrKeyRange;
@@ -1443,12 +1500,9 @@ __global__ __launch_bounds__(256) void verdict_kernel(const FrameDev *__restrict
     uint32_t info = cand ? (kVCand | (n_obs << 12) | n_vis) : 0u;
     if (ok) {
         const double fx = x86_nan(wx / total), fy = x86_nan(wy / total), fz = x86_nan(wz / total);  // :164
-        unsigned long long c0_, c1_, c2_;
-        const int fits = (int)axis_code_of(fx, P.voxel_size, c0_) & (int)axis_code_of(fy, P.voxel_size, c1_) &
-                         (int)axis_code_of(fz, P.voxel_size, c2_);
-        info |= fits ? kVOk : (kVOk | kVKeyRange);
         VerdictRec r;
-        r.key = (c0_ << 42) | (c1_ << 21) | c2_;
+        const bool fits = pack_voxel_key(P, fx, fy, fz, r.key);
+        info |= fits ? kVOk : (kVOk | kVKeyRange);
         r.x = fx; r.y = fy; r.z = fz;
         V.rec[pix] = r;
     }
@@ -1938,14 +1992,48 @@ struct Record {  // 48 bytes on the wire
     uint32_t bgr, pad;
 };
 
-__device__ __forceinline__ uint32_t part_of(unsigned long long key, uint32_t n_parts)
+struct KeyPack {  // the packing as the read-out / exchange kernels need it (by value)
+    long long lo[3], hi[3];
+    uint32_t b[3];
+};
+
+__device__ __forceinline__ void unpack_key_dev(unsigned long long k, const KeyPack &kp, unsigned long long out[3])
 {
-    return (uint32_t)((mix64(key ^ 0x9E3779B97F4A7C15ull) >> 17) % n_parts);
+    out[0] = axis_decode_range((k >> (kp.b[1] + kp.b[2])) & ((1ull << kp.b[0]) - 1ull), kp.lo[0], kp.hi[0]);
+    out[1] = axis_decode_range((k >> kp.b[2]) & ((1ull << kp.b[1]) - 1ull), kp.lo[1], kp.hi[1]);
+    out[2] = axis_decode_range(k & ((1ull << kp.b[2]) - 1ull), kp.lo[2], kp.hi[2]);
+}
+
+// The owner of a voxel: a hash of its three indices, NOT of the packed key -- ranks may pack with different widths
+// until the exchange has agreed on common ones, the owner must not depend on that.
+__device__ __forceinline__ uint32_t part_of(unsigned long long key, KeyPack kb, uint32_t n_parts)
+{
+    unsigned long long i[3];
+    unpack_key_dev(key, kb, i);
+    const unsigned long long h = mix64(i[0] ^ mix64(i[1] ^ mix64(i[2] ^ 0x9E3779B97F4A7C15ull)));
+    return (uint32_t)((h >> 17) % n_parts);
+}
+
+// sfm_fusion_set_key_range on an existing cloud: the same keys in another packing (a key the new packing does not
+// hold raises err; the host then leaves the cloud as it is)
+__global__ __launch_bounds__(256) void rekey_kernel(const unsigned long long *out_key, unsigned long long *dst,
+                                                    unsigned long long n, KeyPack from, KeyPack to, Counters *ctr)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long v[3], code[3];
+        unpack_key_dev(out_key[i], from, v);
+        bool ok = true;
+        for (int a = 0; a < 3; a++)
+            ok = axis_code_range(v[a] == 0x8000000000000000ull ? INT64_MIN : (long long)v[a], to.lo[a], to.hi[a], code[a]) && ok;
+        if (!ok) atomicOr(&ctr->err, kErrKeyRange);
+        dst[i] = (code[0] << (to.b[1] + to.b[2])) | (code[1] << to.b[2]) | code[2];
+    }
 }
 
 // counts[p] += number of output points owned by part p (n_parts <= 1024)
 __global__ __launch_bounds__(256) void partition_count_kernel(const unsigned long long *out_key,
-                                                              unsigned long long n, uint32_t n_parts,
+                                                              unsigned long long n, uint32_t n_parts, KeyPack kb,
                                                               unsigned long long *counts)
 {
     __shared__ unsigned int s_c[1024];
@@ -1953,7 +2041,7 @@ __global__ __launch_bounds__(256) void partition_count_kernel(const unsigned lon
     __syncthreads();
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x)
-        atomicAdd(&s_c[part_of(out_key[i], n_parts)], 1u);
+        atomicAdd(&s_c[part_of(out_key[i], kb, n_parts)], 1u);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_parts; i += blockDim.x)
         if (s_c[i]) atomicAdd(&counts[i], (unsigned long long)s_c[i]);
@@ -1965,7 +2053,7 @@ __global__ __launch_bounds__(256) void partition_count_kernel(const unsigned lon
 __global__ __launch_bounds__(256) void partition_scatter_kernel(const unsigned long long *out_key,
                                                                 const unsigned long long *out_tag,
                                                                 const double *out_xyz, const uint32_t *out_bgr,
-                                                                unsigned long long n, uint32_t n_parts,
+                                                                unsigned long long n, uint32_t n_parts, KeyPack kb,
                                                                 const uint32_t *global_order,
                                                                 unsigned long long *cursors, Record *dst)
 {
@@ -1981,7 +2069,7 @@ __global__ __launch_bounds__(256) void partition_scatter_kernel(const unsigned l
         uint32_t part = 0, rank = 0;
         if (valid) {
             key = out_key[i];
-            part = part_of(key, n_parts);
+            part = part_of(key, kb, n_parts);
             rank = atomicAdd(&s_c[part], 1u);
         }
         __syncthreads();
@@ -2093,21 +2181,15 @@ __global__ __launch_bounds__(256) void iota_kernel(uint32_t *idx, unsigned long 
         idx[i] = (uint32_t)i;
 }
 
-// 21-bit axis code -> the reference's size_t key component (two's complement; 0x100000 = x86 indefinite)
-__device__ __forceinline__ unsigned long long unpack_axis_dev(unsigned long long code)
-{
-    if (code == 0x100000ull) return 0x8000000000000000ull;
-    return (unsigned long long)((long long)(code << 43) >> 43);
-}
-
 // perm: positions in ascending packed-key order, which is the lexicographic order of the three
 // unsigned components (non-negative indices, then the indefinite value, then negative ones, per axis)
 __global__ __launch_bounds__(256) void cloud_gather_kernel(const uint32_t *perm, unsigned long long n,
                                                            const unsigned long long *out_key,
                                                            const unsigned long long *out_tag, const double *out_xyz,
                                                            const uint32_t *out_bgr, const uint32_t *global_order,
-                                                           uint32_t n_global_order, double *dst_xyz, int32_t *dst_bgr,
-                                                           unsigned long long *dst_key, unsigned long long *dst_tag)
+                                                           uint32_t n_global_order, KeyPack kb, double *dst_xyz,
+                                                           int32_t *dst_bgr, unsigned long long *dst_key,
+                                                           unsigned long long *dst_tag)
 {
     for (unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; o < n;
          o += (unsigned long long)gridDim.x * blockDim.x) {
@@ -2119,10 +2201,11 @@ __global__ __launch_bounds__(256) void cloud_gather_kernel(const uint32_t *perm,
         dst_bgr[3 * o + 0] = (int32_t)(c & 255);
         dst_bgr[3 * o + 1] = (int32_t)((c >> 8) & 255);
         dst_bgr[3 * o + 2] = (int32_t)((c >> 16) & 255);
-        const unsigned long long k = out_key[i];
-        dst_key[3 * o + 0] = unpack_axis_dev((k >> 42) & 0x1FFFFF);
-        dst_key[3 * o + 1] = unpack_axis_dev((k >> 21) & 0x1FFFFF);
-        dst_key[3 * o + 2] = unpack_axis_dev(k & 0x1FFFFF);
+        unsigned long long k3[3];
+        unpack_key_dev(out_key[i], kb, k3);
+        dst_key[3 * o + 0] = k3[0];
+        dst_key[3 * o + 1] = k3[1];
+        dst_key[3 * o + 2] = k3[2];
         unsigned long long t = out_tag[i];
         if ((t >> 32) < n_global_order) t = ((unsigned long long)global_order[t >> 32] << 32) | (t & 0xFFFFFFFFull);
         dst_tag[o] = t;

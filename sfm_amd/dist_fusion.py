@@ -225,20 +225,30 @@ class VoxelExchange:
         counts = self.ctx.partition_counts(self.world)
         mark("partition_counts")
         n_local = sum(counts)
-        send = torch.empty(max(n_local, 1) * RECORD_BYTES, dtype=torch.uint8, device=self.device)
-        self.ctx.export_records(send.data_ptr(), n_local * RECORD_BYTES)
-        mark("export_records")
-        send_counts = torch.tensor(counts, dtype=torch.int64, device=self.device)
+        # Every peer learns this rank's record count for it AND this rank's key packing (index range per axis) in one
+        # all-to-all: ranks that saw voxel indices of different ranges pack differently, and records are only
+        # comparable in one common packing -- the hull of all ranges.  The owner of a voxel does not depend on it.
+        lo, hi = self.ctx.key_range() if hasattr(self.ctx, "key_range") else ((0, 0, 0), (0, 0, 0))
+        send_counts = torch.tensor([[n, *lo, *hi] for n in counts], dtype=torch.int64, device=self.device)
         recv_counts = torch.empty_like(send_counts)
         # gloo has no all-to-all on device tensors: stage through the host there (CPU tests and
         # the single-GPU rehearsal of the N>1 path); RCCL ("nccl") moves device memory directly
-        staged = send.is_cuda and dist.get_backend(self.group) == "gloo"
+        staged = send_counts.is_cuda and dist.get_backend(self.group) == "gloo"
         if staged:
             send_counts = send_counts.cpu()
             recv_counts = recv_counts.cpu()
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        rc = [int(x) for x in recv_counts.tolist()]
+        got = recv_counts.tolist()
+        rc = [int(row[0]) for row in got]
+        c_lo = tuple(min([lo[a]] + [int(row[1 + a]) for row in got]) for a in range(3))
+        c_hi = tuple(max([hi[a]] + [int(row[4 + a]) for row in got]) for a in range(3))
+        if (c_lo, c_hi) != (tuple(lo), tuple(hi)):
+            self.ctx.set_key_range(c_lo, c_hi)                 # re-encodes this rank's cloud
+            assert self.ctx.partition_counts(self.world) == counts
         mark("all_to_all counts")
+        send = torch.empty(max(n_local, 1) * RECORD_BYTES, dtype=torch.uint8, device=self.device)
+        self.ctx.export_records(send.data_ptr(), n_local * RECORD_BYTES)
+        mark("export_records")
         n_recv = sum(rc)
         recv = torch.empty(max(n_recv, 1) * RECORD_BYTES, dtype=torch.uint8, device=self.device)
         in_splits = [c * RECORD_BYTES for c in counts]

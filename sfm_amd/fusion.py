@@ -39,7 +39,7 @@ EXPORTS = [
     "sfm_fusion_export_records", "sfm_fusion_merge", "sfm_fusion_set_covisibility",
     "sfm_fusion_partition_counts_noalloc", "sfm_fusion_set_active_range", "sfm_fusion_import_masks",
     "sfm_fusion_clear_imported_masks", "sfm_fusion_export_masks", "sfm_fusion_precompute",
-    "sfm_fusion_add_keyframe_se3", "sfm_fusion_se3_exp",
+    "sfm_fusion_add_keyframe_se3", "sfm_fusion_se3_exp", "sfm_fusion_get_key_range", "sfm_fusion_set_key_range",
 ]
 SFM_RECORD_BYTES = 48
 
@@ -109,6 +109,8 @@ def load_library():
     L.sfm_fusion_get_frame_counts.argtypes = [vp, vp, vp]
     L.sfm_fusion_set_profiling.argtypes = [vp, C.c_int]
     L.sfm_fusion_set_global_order.argtypes = [vp, C.POINTER(u32), u32]
+    L.sfm_fusion_get_key_range.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.sfm_fusion_set_key_range.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sfm_fusion_partition_counts.argtypes = [vp, u32, C.POINTER(u64)]
     L.sfm_fusion_partition_counts_noalloc.argtypes = [vp, u32, C.POINTER(u64)]
     L.sfm_fusion_export_records.argtypes = [vp, vp, u64]
@@ -248,6 +250,18 @@ class FusionContext:
         o = np.ascontiguousarray(order, dtype=np.uint32)
         self._check(self._L.sfm_fusion_set_global_order(
             self._h, o.ctypes.data_as(C.POINTER(C.c_uint32)), o.size))
+
+    def key_range(self):
+        """(lo, hi): per axis the voxel indices the exact 64-bit key packing in use holds."""
+        lo = (C.c_int64 * 3)()
+        hi = (C.c_int64 * 3)()
+        self._check(self._L.sfm_fusion_get_key_range(self._h, lo, hi))
+        return tuple(int(x) for x in lo), tuple(int(x) for x in hi)
+
+    def set_key_range(self, lo, hi):
+        a = (C.c_int64 * 3)(*[int(x) for x in lo])
+        b = (C.c_int64 * 3)(*[int(x) for x in hi])
+        self._check(self._L.sfm_fusion_set_key_range(self._h, a, b))
 
     def partition_counts(self, n_parts: int):
         counts = (C.c_uint64 * n_parts)()

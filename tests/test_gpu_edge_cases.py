@@ -136,12 +136,69 @@ def test_rerun_is_idempotent_and_capacities_grow():
     assert e.value.code == fusion.SFM_E_TABLE_FULL
 
 
-def test_key_range_overflow_is_reported_not_hidden():
+def _shifted(frames, offset):
+    """The same scene somewhere else in the world: every pose translated by `offset` (raw units)."""
+    out = []
+    for f in frames:
+        T_wk = np.array(f["T_wk"], dtype=np.float64)
+        T_wk[:3, 3] += offset
+        T_kw = np.array(f["T_kw"], dtype=np.float64)
+        T_kw[:3, 3] = -T_kw[:3, :3] @ T_wk[:3, 3]
+        out.append(dict(f, T_wk=T_wk, T_kw=T_kw))
+    return out
+
+
+def test_voxel_indices_beyond_the_default_key_range_stay_exact():
+    """Voxel indices outside +-(2^20 - 1) (dense_reconstruction.cpp:270-274 has no limit): the run notices, scans the
+    index ranges and packs the 64-bit key for exactly those -- the cloud still equals the oracle's three size_t."""
     frames = scenes.plane_pair()
-    _, gp = both_params(voxel_size=1e-6)      # 40 / 1e-6 = 4e7 voxels from the origin > 2^20
+    op, gp = both_params(voxel_size=1e-6)      # 40 / 1e-6 = 4e7 voxels from the origin > 2^20, on one axis
+    want = oracle.fuse(frames, op)
+    assert int(want.key.view(np.int64).max()) > 2 ** 21
+    assert_same_cloud(run_gpu(frames, gp), want)
+    # a room far from the origin in all three axes, negative side included: small extents, huge offsets
+    seq = synth.make_sequence(6, 96, 72, K=(196.8, 196.8, 47.5, 35.5), window=2)
+    frames = _shifted(seq.frame_dicts(), np.array([5.0e8, -3.0e8, 2.0e9]))
+    op, gp = both_params(voxel_size=10.0, T_dist=500.0)
+    want = oracle.fuse(frames, op)
+    k = want.key.view(np.int64)
+    assert k[:, 0].min() > 4e7 and k[:, 1].max() < -2e7 and k[:, 2].min() > 1e8 and want.key.shape[0] > 5000
+    ctx = fusion.FusionContext(gp)
+    for f in frames:
+        ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+    for i, f in enumerate(frames):
+        ctx.set_neighbors(i, f["nbrs"])
+    assert ctx.key_range() == ((-1048575,) * 3, (1048575,) * 3)
+    ctx.run()
+    lo, hi = ctx.key_range()
+    for ax in range(3):
+        assert lo[ax] == k[:, ax].min() or lo[ax] < k[:, ax].min()    # (the two-phase scan sees rejected-by-mask pixels too)
+        assert hi[ax] >= k[:, ax].max() and hi[ax] - lo[ax] < 4000
+    xyz, bgr, key, tag = ctx.read_points()
+    assert np.array_equal(key, want.key) and np.array_equal(tag, want.tag)
+    assert np.array_equal(xyz.view(np.uint64), want.xyz.view(np.uint64)) and np.array_equal(bgr, want.bgr)
+    st = ctx.stats()
+    assert st["n_vox"] == want.counters["n_vox"] and st["n_hit"] == want.counters["n_hit"]
+    # the ctx keeps the ranges: the next run needs no scan and gives the same cloud
+    ctx.run()
+    assert ctx.key_range() == (lo, hi) and np.array_equal(ctx.read_points()[2], want.key)
+    # ranges that do not hold the cloud at hand are refused and change nothing
+    with pytest.raises(fusion.FusionError) as e:
+        ctx.set_key_range((0, 0, 0), (100, 100, 100))
+    assert e.value.code == fusion.SFM_E_KEY_RANGE and ctx.key_range() == (lo, hi)
+    # wider ones re-encode it in place
+    ctx.set_key_range([x - 1000 for x in lo], [x + 5 for x in hi])
+    assert np.array_equal(ctx.read_points()[2], want.key) and np.array_equal(ctx.read_points()[3], want.tag)
+    ctx.close()
+
+
+def test_a_cloud_no_exact_64_bit_key_can_hold_is_an_error():
+    seq = synth.make_sequence(4, 48, 36, K=(98.4, 98.4, 23.5, 17.5), window=2)
+    frames = seq.frame_dicts()
+    _, gp = both_params(voxel_size=1e-6, T_dist=500.0)   # metres of wall in nanometre voxels: about 30 bits per axis
     with pytest.raises(fusion.FusionError) as e:
         run_gpu(frames, gp)
-    assert e.value.code == fusion.SFM_E_KEY_RANGE
+    assert e.value.code == fusion.SFM_E_KEY_RANGE and "63" in str(e.value)
 
 
 def test_argument_errors():

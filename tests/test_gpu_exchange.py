@@ -80,3 +80,60 @@ def test_read_points_reports_global_orders_without_merge():
     with pytest.raises(fusion.FusionError):
         ctx.set_global_order([3, 2, 1, 0])
     ctx.close()
+
+
+def test_ranks_with_different_key_ranges_agree_on_their_hull():
+    """Two components far apart: each rank's run ends with its own key packing; the exchange (VoxelExchange over a
+    one-rank gloo group per ctx is not possible, so its steps by hand) sets the hull on both before the records
+    travel, and the owners' union is the oracle's cloud."""
+    import torch
+    seq = synth.make_sequence(8, 64, 48, K=(131.25, 131.25, 31.5, 23.5), window=2, components=2)
+    frames = seq.frame_dicts()
+    for i, off in ((0, np.array([4.0e8, 0.0, 0.0])), (1, np.array([-2.0e8, 6.0e4, -3.0e4]))):
+        for f in frames[4 * i:4 * i + 4]:
+            f["T_wk"] = np.array(f["T_wk"]); f["T_wk"][:3, 3] += off
+            f["T_kw"] = np.array(f["T_kw"]); f["T_kw"][:3, 3] = -f["T_kw"][:3, :3] @ f["T_wk"][:3, 3]
+    op, gp = both_params(voxel_size=30.0, T_dist=500.0)
+    want = oracle.fuse(frames, op)
+    ctxs = []
+    for r in range(2):
+        ctx = fusion.FusionContext(gp)
+        for f in frames[4 * r:4 * r + 4]:
+            ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+        for i, f in enumerate(frames[4 * r:4 * r + 4]):
+            ctx.set_neighbors(i, [j - 4 * r for j in f["nbrs"]])
+        ctx.set_global_order(list(range(4 * r, 4 * r + 4)))
+        ctx.run()
+        ctxs.append(ctx)
+    ranges = [c.key_range() for c in ctxs]
+    assert ranges[0] != ranges[1]
+    counts_before = [c.partition_counts(2) for c in ctxs]         # owners do not depend on the packing
+    lo = tuple(min(r[0][a] for r in ranges) for a in range(3))
+    hi = tuple(max(r[1][a] for r in ranges) for a in range(3))
+    for c in ctxs:
+        c.set_key_range(lo, hi)
+    counts = [c.partition_counts(2) for c in ctxs]
+    assert counts == counts_before
+    sends = []
+    for r, ctx in enumerate(ctxs):
+        n = sum(counts[r])
+        buf = torch.empty(max(n, 1) * fusion.SFM_RECORD_BYTES, dtype=torch.uint8, device="cuda")
+        ctx.export_records(buf.data_ptr(), n * fusion.SFM_RECORD_BYTES)
+        sends.append(buf)
+    torch.cuda.synchronize()
+    got = []
+    for owner, ctx in enumerate(ctxs):
+        pieces = []
+        for r in range(2):
+            start = sum(counts[r][:owner]) * fusion.SFM_RECORD_BYTES
+            pieces.append(sends[r][start:start + counts[r][owner] * fusion.SFM_RECORD_BYTES])
+        recv = torch.cat(pieces)
+        torch.cuda.synchronize()
+        ctx.merge(recv.data_ptr(), recv.numel() // fusion.SFM_RECORD_BYTES)
+        got.append(ctx.read_points())
+    xyz = np.concatenate([g[0] for g in got]); bgr = np.concatenate([g[1] for g in got])
+    key = np.concatenate([g[2] for g in got]); tag = np.concatenate([g[3] for g in got])
+    xyz, bgr, key, tag = oracle.sort_by_key(xyz, bgr, key, tag)
+    assert np.array_equal(key, want.key) and np.array_equal(tag, want.tag) and np.array_equal(xyz, want.xyz)
+    for c in ctxs:
+        c.close()
