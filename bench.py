@@ -221,6 +221,35 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
         except Exception:
             traffic = None
 
+    # The roofs that bind this kernel, beside the contracted HBM figure (profiles/bounds_latest.json, made by
+    # tools/profile_pass.sh + tools/profile_summary.py from rocprofv3 SQ counters and the micro-benchmarks):
+    #   fp64   VALU-issue floor: wave instructions counted by SQ_INSTS_VALU x 4 cycles on 1024 SIMDs at 2.4 GHz
+    #   chain  keyframes x the smallest link: the device-wide barrier alone, and the chain with all arithmetic
+    #          removed (accept_chain_kernel)
+    fp64_roof = chain_roof = None
+    bpath = os.path.join(ROOT, "profiles", "bounds_latest.json")
+    if os.path.exists(bpath) and avg_launch_s > 0:
+        try:
+            bj = json.load(open(bpath))
+            if bj.get("workload") == args.workload and not args.frames and bj.get("kernel") == kernel_name and world == 1:
+                floor = bj["valu_issue_floor_us"]
+                fp64_roof = {"valu_wave_insts_per_launch": bj["valu_insts_per_launch"], "issue_floor_us": floor,
+                             "frac": floor * 1e-6 / avg_launch_s,
+                             "issue_floor_us_at_measured_rate": bj.get("valu_issue_floor_us_measured_rate"),
+                             "frac_at_measured_rate": (bj["valu_issue_floor_us_measured_rate"] * 1e-6 / avg_launch_s
+                                                       if bj.get("valu_issue_floor_us_measured_rate") else None),
+                             "source": "profiles/%s_summary.json (rocprofv3 --pmc SQ_INSTS_VALU), tools/valu_bench.hip" % bj["tag"]}
+                kpl = (plan.end - plan.first) / launches
+                chain_roof = {"keyframes_per_launch": kpl, "barrier_us": bj.get("barrier_us"),
+                              "barrier_floor_frac": (kpl * bj["barrier_us"] * 1e-6 / avg_launch_s) if bj.get("barrier_us") else None,
+                              "accept_link_us": bj.get("accept_link_us"),
+                              "accept_link_floor_frac": (kpl * bj["accept_link_us"] * 1e-6 / avg_launch_s)
+                              if bj.get("accept_link_us") else None,
+                              "us_per_keyframe": avg_launch_s * 1e6 / kpl,
+                              "source": "tools/barrier_bench.hip; bench.py --two-phase (accept_chain_kernel)"}
+        except Exception:
+            fp64_roof = chain_roof = None
+
     px_total = n_kf * W * H   # the whole sequence, whatever the number of ranks: strong scaling
     value = px_total * args.steps / dt
     out = {
@@ -262,6 +291,8 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
                 "achieved": scan_bytes(pst) / launches / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0},
             "whole_step_frac": total_bytes(st) / (st["last_run_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             if st["last_run_ms"] > 0 else None,
+            "fp64": fp64_roof,
+            "chain": chain_roof,
         },
         "table": {"capacity": st["table_capacity"], "used": st["table_used"],
                   "load_factor": st["table_used"] / max(1, st["table_capacity"]),

@@ -38,6 +38,57 @@ out["dominant_kernel"] = short
 out[short + "_hbm_bytes_per_launch"] = hbm
 out[short + "_fetch_raw_bytes_per_launch"] = fetch_kb * 1024.0
 out[short + "_write_bytes_per_launch"] = write_kb * 1024.0
+# optional: SQ instruction counters of the same command (tools/profile_pass.sh <tag> valu) and the micro-benchmarks
+# (gpurun_out/<tag>_valu_bench.txt, <tag>_barrier_bench.txt) -> profiles/bounds_latest.json, read by bench.py for
+# roofline.fp64 and roofline.chain
+vf = glob.glob(f"gpurun_out/{tag}_valu/*/*counter_collection.csv")
+if vf:
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.Counter()
+    for r in csv.DictReader(open(vf[0])):
+        if "sfm::" in r["Kernel_Name"]:
+            kname = r["Kernel_Name"].split("(")[0]
+            agg[kname][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "SQ_WAVES":
+                launches[kname] += 1
+    out["sq"] = {kname: dict(launches=launches[kname], **{c: v / max(1, launches[kname]) for c, v in cs.items()})
+                 for kname, cs in agg.items()}
+    bounds = {"workload": out["workload"], "tag": tag, "kernel": short}
+    sq = out["sq"].get(k)
+    if sq:
+        # CDNA4: a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles, FP64 fma/mul/add included
+        # (tools/valu_bench.hip); 256 CUs x 4 SIMDs; 2.4 GHz peak engine clock
+        bounds["valu_insts_per_launch"] = sq.get("SQ_INSTS_VALU", 0.0)
+        bounds["valu_issue_floor_us"] = sq.get("SQ_INSTS_VALU", 0.0) * 4.0 / (1024 * 2.4e9) * 1e6
+        bounds["sq_per_launch"] = sq
+    import re
+    try:
+        txt = open(f"gpurun_out/{tag}_barrier_bench.txt").read()
+        rows = re.findall(r"fenced (\d) traffic (\d) levels (\d) threads\s+(\d+) G\s+(\d+): rc 0 abort 0\s+([0-9.]+) us per barrier", txt)
+        pick = [float(r[5]) for r in rows if r[0] == "0" and r[1] == "0" and r[2] == "2" and r[4] == "256"]
+        allr = [float(r[5]) for r in rows if r[0] == "0" and r[4] == "256"]
+        bounds["barrier_us"] = min(pick) if pick else (min(allr) if allr else None)
+        bounds["barrier_note"] = ("tools/barrier_bench.hip: two-level counters + flag, relaxed agent-scope atomics, 256 "
+                                  "co-resident workgroups, nothing between the barriers (the latency of the barrier alone)")
+    except OSError:
+        pass
+    try:
+        # measured cost of a plain wave64 VALU instruction (loop overhead included): v_add_f64 row of tools/valu_bench.hip
+        txt = open(f"gpurun_out/{tag}_valu_bench.txt").read()
+        m = re.search(r"v_add_f64\s+[0-9.]+ ms\s+([0-9.]+) ns per step", txt)
+        if m and sq:
+            bounds["valu_ns_per_inst_measured"] = float(m.group(1))
+            bounds["valu_issue_floor_us_measured_rate"] = sq.get("SQ_INSTS_VALU", 0.0) * float(m.group(1)) / 1024 * 1e-3
+    except OSError:
+        pass
+    try:
+        # the chain with its arithmetic removed: accept_chain_kernel alone (bench.py --two-phase), per keyframe
+        tp = json.loads([l for l in open(f"gpurun_out/{tag}_two_phase.json") if l.startswith("{")][-1])
+        bounds["accept_link_us"] = tp["two_phase"]["phase_b_ms"] * 1e3 / tp["config"]["keyframes"]
+        bounds["phase_a_us_per_keyframe"] = tp["two_phase"]["phase_a_ms"] * 1e3 / tp["config"]["keyframes"]
+    except (OSError, KeyError, IndexError):
+        pass
+    json.dump(bounds, open("profiles/bounds_latest.json", "w"), indent=1)
 json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 json.dump({"workload": out["workload"], "tag": tag, "hbm_bytes_per_launch": hbm,
            "kernel": short,
