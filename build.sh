@@ -18,6 +18,9 @@ g++ -std=c++17 -O2 -Wall -pthread sfm_amd/cpp/facade_example.cpp -Lbuild -lsfm_f
   -Wl,-rpath,'$ORIGIN/../lib' -o sfm_amd/cpp/facade_example
 g++ -std=c++17 -O2 -Wall -pthread sfm_amd/cpp/replay_reconstruct.cpp -Lbuild -lsfm_fusion \
   -Wl,-rpath,'$ORIGIN/../lib' -o sfm_amd/cpp/replay_reconstruct
+# multi-GPU C++ host (RCCL); run at one rank by tests/test_gpu_replay.py
+g++ -std=c++17 -O2 -Wall -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include sfm_amd/cpp/dist_reconstruct.cpp -Lbuild -lsfm_fusion \
+  -L/opt/rocm/lib -lrccl -lamdhip64 -Wl,-rpath,'$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib -o sfm_amd/cpp/dist_reconstruct
 # host-only formatter probe used by tests/test_writer_parity.py
 g++ -std=c++17 -O2 -Wall -pthread tests/cpp/writer_probe.cpp -o build/writer_probe
 g++ -std=c++17 -O2 -Wall tests/cpp/recording_probe.cpp -lz -o build/recording_probe

@@ -1,0 +1,271 @@
+// dist_fusion.hpp -- C++ host of the multi-GPU path: one process per GPU, RCCL over xGMI, the C ABI underneath.
+// The C++ twin of sfm_amd/dist_fusion.py (SequenceSplit + VoxelExchange); no reference counterpart (the reference is
+// one process).  One keyframe sequence is cut into contiguous blocks, one per rank:
+//   1. every rank but the first computes its block's mask-independent verdicts (sfm_fusion_precompute) while its
+//      predecessors chain;
+//   2. a rank receives the visibility masks its predecessors left on its keyframes (ncclRecv, rank order), fuses its
+//      block (sfm_fusion_run), and sends the masks of later ranks' keyframes on (ncclSend);
+//   3. voxel exchange: winners bucketed by owner = hash(voxel indices) mod N, counts and key ranges by ncclAllGather,
+//      48-byte records by grouped ncclSend/ncclRecv (every peer pair on its own xGMI link), sfm_fusion_merge.
+// The union of the ranks' clouds is bit-identical to DenseReconstruction::fuse() on one GPU.
+// Header-only; build with -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ and link -lsfm_fusion -lrccl -lamdhip64.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "dense_reconstruction.hpp"
+
+namespace sfm_amd {
+
+struct RankPlan {
+    std::size_t first = 0, end = 0;                         // block [first, end) of the selected-keyframe order
+    std::vector<std::size_t> frames;                        // ascending: the block and every neighbour of a keyframe in it
+    std::map<int, std::vector<std::size_t>> sends, recvs;   // rank -> keyframes whose masks travel
+    std::map<std::size_t, std::uint32_t> local;             // keyframe -> ctx order index
+};
+
+// nbrs[i] = neighbours of keyframe i (positions in the processing order); px[i] = its pixels (the block weight)
+inline std::vector<RankPlan> plan_sequence(const std::vector<std::vector<std::uint32_t>> &nbrs,
+                                           const std::vector<std::uint64_t> &px, int world)
+{
+    const std::size_t n = nbrs.size();
+    std::uint64_t total = 0;
+    for (auto w : px) total += w;
+    std::vector<std::size_t> cuts{0};
+    std::uint64_t acc = 0;
+    std::size_t i = 0;
+    for (int r = 1; r < world; r++) {
+        const double want = (double)total * r / world;
+        while (i < n && (double)acc + px[i] / 2.0 <= want) acc += px[i++];
+        cuts.push_back(i);
+    }
+    cuts.push_back(n);
+    std::vector<int> owner(n, 0);
+    for (int r = 0; r < world; r++)
+        for (std::size_t g = cuts[r]; g < cuts[r + 1]; g++) owner[g] = r;
+    std::vector<RankPlan> plans(world);
+    std::vector<std::map<int, std::set<std::size_t>>> marks(world);
+    for (int r = 0; r < world; r++) {
+        RankPlan &p = plans[r];
+        p.first = cuts[r];
+        p.end = cuts[r + 1];
+        std::set<std::size_t> fr;
+        for (std::size_t g = p.first; g < p.end; g++) {
+            fr.insert(g);
+            for (auto j : nbrs[g]) {
+                fr.insert(j);
+                if (j >= p.end) marks[r][owner[j]].insert(j);  // a keyframe marks its LATER neighbours only
+            }
+        }
+        p.frames.assign(fr.begin(), fr.end());
+        for (std::size_t k = 0; k < p.frames.size(); k++) p.local[p.frames[k]] = (std::uint32_t)k;
+    }
+    for (int q = 0; q < world; q++)
+        for (auto &[t, s] : marks[q]) {
+            plans[q].sends[t].assign(s.begin(), s.end());
+            plans[t].recvs[q].assign(s.begin(), s.end());
+        }
+    return plans;
+}
+
+class DistributedDenseReconstruction {
+public:
+    DistributedDenseReconstruction(const Map &map, int rank, int world, ncclComm_t comm, int device)
+        : map_(map), rank_(rank), world_(world), comm_(comm), device_(device)
+    {
+        sfm_fusion_default_params(&params_);
+    }
+    sfm_fusion_params &params() { return params_; }
+    const sfm_fusion_stats &stats() const { return stats_; }
+
+    // This rank's share of the cloud (the voxels it owns), sorted by voxel key; tags carry positions in the
+    // selected-keyframe order, as DenseReconstruction::fuse() gives them.
+    Cloud fuse()
+    {
+        hip(hipSetDevice(device_), "hipSetDevice");
+        hipStream_t stream = nullptr;
+        hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+        // selection and neighbours exactly as the one-GPU facade (dense_reconstruction.cpp:32-38, map.cpp:152-160)
+        std::set<std::size_t> sel;
+        for (const auto &[e, count] : map_.covisibility_edge)
+            if (count >= 100) { sel.insert(e.first); sel.insert(e.second); }
+        const std::vector<std::size_t> order(sel.begin(), sel.end());
+        std::map<std::size_t, std::uint32_t> pos;
+        for (std::size_t i = 0; i < order.size(); i++) pos[order[i]] = (std::uint32_t)i;
+        std::vector<std::vector<std::uint32_t>> nb(order.size());
+        for (const auto &[e, count] : map_.covisibility_edge) {
+            if (count <= 100) continue;
+            nb[pos.at(e.first)].push_back(pos.at(e.second));
+            nb[pos.at(e.second)].push_back(pos.at(e.first));
+        }
+        std::vector<std::uint64_t> px(order.size());
+        for (std::size_t i = 0; i < order.size(); i++) {
+            std::sort(nb[i].begin(), nb[i].end());
+            const KeyFrame &k = map_.keyframes.at(order[i]);
+            px[i] = (std::uint64_t)k.width * k.height;
+        }
+        const RankPlan plan = plan_sequence(nb, px, world_)[rank_];
+
+        sfm_fusion_ctx *ctx = nullptr;
+        if (sfm_fusion_create(&params_, device_, stream, &ctx) != SFM_OK)
+            throw std::runtime_error("sfm_fusion_create failed (no HIP device?)");
+        auto check = [&](int rc) {
+            if (rc != SFM_OK) {
+                const std::string msg = sfm_fusion_last_error(ctx);
+                sfm_fusion_destroy(ctx);
+                throw std::runtime_error("sfm_fusion: " + msg);
+            }
+        };
+        std::vector<std::uint32_t> global_order;
+        for (std::size_t g : plan.frames) {
+            const KeyFrame &k = map_.keyframes.at(order[g]);
+            const double K[4] = {k.K.fx, k.K.fy, k.K.cx, k.K.cy};
+            check(sfm_fusion_add_keyframe(ctx, plan.local.at(g), k.width, k.height, k.depth, k.depth_step, k.img, k.img_step, K,
+                                          k.T_wk, k.T_kw, SFM_MEM_HOST));
+            global_order.push_back((std::uint32_t)g);
+        }
+        for (std::size_t g = plan.first; g < plan.end; g++) {
+            std::vector<std::uint32_t> loc;
+            for (auto j : nb[g]) loc.push_back(plan.local.at(j));
+            check(sfm_fusion_set_neighbors(ctx, plan.local.at(g), loc.data(), (std::uint32_t)loc.size()));
+        }
+        check(sfm_fusion_set_global_order(ctx, global_order.data(), (std::uint32_t)global_order.size()));
+        const std::uint32_t a0 = plan.first < plan.end ? plan.local.at(plan.first) : 0;
+        check(sfm_fusion_set_active_range(ctx, a0, a0 + (std::uint32_t)(plan.end - plan.first)));
+
+        // 1. phase A while the predecessors chain (the first rank has nobody to wait for: fused chain)
+        if (rank_ > 0 && plan.end > plan.first) check(sfm_fusion_precompute(ctx));
+        // 2. masks in, this block's chain, masks out
+        auto bytes_of = [&](const std::vector<std::size_t> &fr) {
+            std::uint64_t b = 0;
+            for (auto g : fr) b += px[g];
+            return b;
+        };
+        for (const auto &[q, fr] : plan.recvs) {
+            DevBuf buf(bytes_of(fr));
+            nccl(ncclRecv(buf.p, buf.n, ncclUint8, q, comm_, stream), "ncclRecv masks");
+            hip(hipStreamSynchronize(stream), "sync");
+            std::uint64_t off = 0;
+            for_runs(plan, fr, [&](std::uint32_t first, std::uint32_t count, std::uint64_t nbytes) {
+                check(sfm_fusion_import_masks(ctx, first, count, (const char *)buf.p + off, nbytes));
+                off += nbytes;
+            }, px);
+        }
+        check(sfm_fusion_run(ctx));
+        for (const auto &[t, fr] : plan.sends) {
+            DevBuf buf(bytes_of(fr));
+            std::uint64_t off = 0;
+            for_runs(plan, fr, [&](std::uint32_t first, std::uint32_t count, std::uint64_t nbytes) {
+                check(sfm_fusion_export_masks(ctx, first, count, (char *)buf.p + off, nbytes));
+                off += nbytes;
+            }, px);
+            nccl(ncclSend(buf.p, buf.n, ncclUint8, t, comm_, stream), "ncclSend masks");
+            hip(hipStreamSynchronize(stream), "sync");
+        }
+        // 3. voxel exchange
+        std::vector<std::uint64_t> counts(world_);
+        check(sfm_fusion_partition_counts(ctx, (std::uint32_t)world_, counts.data()));
+        const int row = world_ + 6;  // my record count for every owner, then my key range (lo[3], hi[3])
+        std::vector<std::int64_t> mine(row), all((std::size_t)row * world_);
+        for (int p = 0; p < world_; p++) mine[p] = (std::int64_t)counts[p];
+        check(sfm_fusion_get_key_range(ctx, &mine[world_], &mine[world_ + 3]));
+        {
+            DevBuf s(row * 8), r((std::uint64_t)row * 8 * world_);
+            hip(hipMemcpyAsync(s.p, mine.data(), row * 8, hipMemcpyHostToDevice, stream), "H2D");
+            nccl(ncclAllGather(s.p, r.p, row, ncclInt64, comm_, stream), "ncclAllGather");
+            hip(hipMemcpyAsync(all.data(), r.p, (std::size_t)row * 8 * world_, hipMemcpyDeviceToHost, stream), "D2H");
+            hip(hipStreamSynchronize(stream), "sync");
+        }
+        std::int64_t lo[3], hi[3];
+        for (int a = 0; a < 3; a++) {
+            lo[a] = mine[world_ + a];
+            hi[a] = mine[world_ + 3 + a];
+            for (int p = 0; p < world_; p++) {
+                lo[a] = std::min(lo[a], all[(std::size_t)p * row + world_ + a]);
+                hi[a] = std::max(hi[a], all[(std::size_t)p * row + world_ + 3 + a]);
+            }
+        }
+        check(sfm_fusion_set_key_range(ctx, lo, hi));  // one packing on every rank (re-encodes this rank's cloud)
+        check(sfm_fusion_partition_counts(ctx, (std::uint32_t)world_, counts.data()));
+        std::uint64_t n_local = 0, n_recv = 0;
+        for (auto c : counts) n_local += c;
+        for (int p = 0; p < world_; p++) n_recv += (std::uint64_t)all[(std::size_t)p * row + rank_];
+        DevBuf send(n_local * SFM_RECORD_BYTES), recv(n_recv * SFM_RECORD_BYTES);
+        check(sfm_fusion_export_records(ctx, send.p, n_local * SFM_RECORD_BYTES));
+        nccl(ncclGroupStart(), "ncclGroupStart");
+        std::uint64_t so = 0, ro = 0;
+        for (int p = 0; p < world_; p++) {
+            const std::uint64_t sb = counts[p] * SFM_RECORD_BYTES, rb = (std::uint64_t)all[(std::size_t)p * row + rank_] * SFM_RECORD_BYTES;
+            if (sb) nccl(ncclSend((char *)send.p + so, sb, ncclUint8, p, comm_, stream), "ncclSend records");
+            if (rb) nccl(ncclRecv((char *)recv.p + ro, rb, ncclUint8, p, comm_, stream), "ncclRecv records");
+            so += sb;
+            ro += rb;
+        }
+        nccl(ncclGroupEnd(), "ncclGroupEnd");
+        hip(hipStreamSynchronize(stream), "sync");
+        check(sfm_fusion_merge(ctx, recv.p, n_recv));
+        std::uint64_t n = 0;
+        check(sfm_fusion_num_points(ctx, &n));
+        Cloud c;
+        c.xyz.resize(3 * n); c.bgr.resize(3 * n); c.key.resize(3 * n); c.tag.resize(n);
+        check(sfm_fusion_read_points(ctx, c.xyz.data(), c.bgr.data(), c.key.data(), c.tag.data()));
+        check(sfm_fusion_get_stats(ctx, &stats_));
+        sfm_fusion_destroy(ctx);
+        (void)hipStreamDestroy(stream);
+        return c;
+    }
+
+private:
+    struct DevBuf {
+        void *p = nullptr;
+        std::uint64_t n;
+        explicit DevBuf(std::uint64_t bytes) : n(bytes)
+        {
+            if (hipMalloc(&p, std::max<std::uint64_t>(bytes, 16)) != hipSuccess) throw std::runtime_error("hipMalloc");
+        }
+        ~DevBuf() { (void)hipFree(p); }
+        DevBuf(const DevBuf &) = delete;
+    };
+    static void hip(hipError_t e, const char *what)
+    {
+        if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    }
+    static void nccl(ncclResult_t e, const char *what)
+    {
+        if (e != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(e));
+    }
+    // consecutive runs of ctx order indices among the keyframes `fr`
+    template <typename F>
+    static void for_runs(const RankPlan &plan, const std::vector<std::size_t> &fr, F &&f, const std::vector<std::uint64_t> &px)
+    {
+        std::size_t i = 0;
+        while (i < fr.size()) {
+            const std::uint32_t first = plan.local.at(fr[i]);
+            std::uint32_t count = 0;
+            std::uint64_t nbytes = 0;
+            while (i < fr.size() && plan.local.at(fr[i]) == first + count) {
+                nbytes += px[fr[i]];
+                count++;
+                i++;
+            }
+            f(first, count, nbytes);
+        }
+    }
+
+    const Map &map_;
+    int rank_, world_;
+    ncclComm_t comm_;
+    int device_;
+    sfm_fusion_params params_{};
+    sfm_fusion_stats stats_{};
+};
+
+}  // namespace sfm_amd

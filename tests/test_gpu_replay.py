@@ -63,6 +63,29 @@ def test_cli_from_replay_dump(tmp_path):
     assert open(out).read() == buf.getvalue()
 
 
+def test_cpp_multi_gpu_host_at_one_rank(tmp_path, fusion_path):
+    """sfm_amd/cpp/dist_reconstruct: the C++ host of the multi-GPU path (block plan, mask hand-over, RCCL exchange:
+    allgather of counts and key ranges, grouped send/recv of records, owner merge) run as ONE rank -- every RCCL call
+    is made, with itself as the only peer -- must write the one-GPU cloud."""
+    if fusion_path != "chain":
+        pytest.skip("one run of the executable")
+    m = small_map(n=6, W=64, H=48)
+    want, _ = oracle_cloud(m, voxel_size=10.0, T_dist=500.0)
+    path = str(tmp_path / "scene.sfmr")
+    replay.write_replay(path, m)
+    buf = io.StringIO()
+    fusion.write_cloud(buf, want.xyz, want.bgr)
+    exe = os.path.join(ROOT, "sfm_amd", "cpp", "dist_reconstruct")
+    assert os.path.exists(exe), "run ./build.sh"
+    out = str(tmp_path / "dist.txt")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, path, out, "--voxel-size", "10", "--t-dist", "500"], capture_output=True, text=True, timeout=240,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rank 0 of 1: %d owned points" % want.key.shape[0] in r.stdout
+    assert open(out + ".rank0").read() == buf.getvalue()
+
+
 def test_in_library_selection_and_neighbour_rules():
     """sfm_fusion_set_covisibility: all keyframes + raw edge counts in, the
     library applies count >= 100 / count > 100 itself.  Same cloud as the facade-side rules; tags
