@@ -208,6 +208,13 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
     chain = bool(pst["fused_chain"])
     kernel_name = "fuse_chain_kernel" if chain else "observe_frame_kernel"
     kernel_bytes = observe_bytes(pst) + (scan_bytes(pst) if chain else 0)
+    if pst["precomputed"]:
+        # --two-phase (and ranks > 0 of a split sequence): the timed chain is accept_chain_kernel, which reads every
+        # pixel's verdict word and its first four stored hit pixels (4 + 16 B, dense), the mask byte of the pixels that
+        # reach geometric_check (<= 1 B per pixel), the 32-byte fused point of an accepted pixel, and writes its
+        # 40-byte list record and one mask byte per kept observation in a later keyframe (<= N_hit)
+        kernel_name = "accept_chain_kernel"
+        kernel_bytes = 21 * pst["n_px"] + 72 * pst["n_acc"] + pst["n_hit"]
     bytes_per_launch = kernel_bytes / launches
     scan_avg_s = pst["scan_kernel_sum_ms"] * 1e-3 / launches
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
