@@ -32,18 +32,42 @@ struct RankPlan {
     std::map<std::size_t, std::uint32_t> local;             // keyframe -> ctx order index
 };
 
+// Relative cost of a keyframe (per pixel) as rank 0's fused chain, as a later rank's phase A (verdicts) and as its
+// phase B (accept chain), measured on one MI355X.  Only the ratios matter, and only for speed.
+struct SplitCost {
+    double fused = 39.0, verdict = 42.0, accept = 14.3;
+    bool equal_blocks = false;
+};
+
+// Share of the sequence each rank's block gets: every rank's phase A ends just when its predecessor's chain does
+// (rank 1's block is fused/verdict of rank 0's, every later one (1 + accept/verdict) times the one before).
+inline std::vector<double> block_shares(int world, const SplitCost &c = SplitCost{})
+{
+    std::vector<double> s((std::size_t)world, 1.0);
+    if (!c.equal_blocks)
+        for (int r = 1; r < world; r++) s[r] = r == 1 ? c.fused / c.verdict : s[r - 1] * (1.0 + c.accept / c.verdict);
+    double total = 0;
+    for (double v : s) total += v;
+    for (double &v : s) v /= total;
+    return s;
+}
+
 // nbrs[i] = neighbours of keyframe i (positions in the processing order); px[i] = its pixels (the block weight)
 inline std::vector<RankPlan> plan_sequence(const std::vector<std::vector<std::uint32_t>> &nbrs,
-                                           const std::vector<std::uint64_t> &px, int world)
+                                           const std::vector<std::uint64_t> &px, int world,
+                                           const SplitCost &cost = SplitCost{})
 {
     const std::size_t n = nbrs.size();
     std::uint64_t total = 0;
     for (auto w : px) total += w;
+    const std::vector<double> shares = block_shares(world, cost);
     std::vector<std::size_t> cuts{0};
     std::uint64_t acc = 0;
     std::size_t i = 0;
+    double upto = 0;
     for (int r = 1; r < world; r++) {
-        const double want = (double)total * r / world;
+        upto += shares[r - 1];
+        const double want = (double)total * upto;
         while (i < n && (double)acc + px[i] / 2.0 <= want) acc += px[i++];
         cuts.push_back(i);
     }

@@ -62,16 +62,41 @@ def shard_components(nbrs: Sequence[Sequence[int]], weights: Sequence[int], worl
     return [sorted(x) for x in out]
 
 
-def split_blocks(weights: Sequence[int], world: int) -> list:
-    """Cuts keyframes 0..n-1 into `world` contiguous blocks of about equal weight (pixels).  Returns
-    [(first, end)] per rank; a rank may get an empty block when there are fewer keyframes than ranks."""
+# Relative cost of a keyframe (per pixel) in the three roles a block can play, measured on one MI355X on the C3
+# workload: fused chain on rank 0, phase A (mask-independent verdicts) and phase B (accept
+# chain) on the later ranks.  Only the ratios matter, and only for speed: any split is exact.
+PIPELINE_COST = (39.0, 42.0, 14.3)
+
+
+def block_shares(world: int, cost=PIPELINE_COST) -> list:
+    """Share of the sequence each rank's block gets.  cost=None: equal shares.  Otherwise the shares that let every
+    rank finish its phase A just when its predecessor finishes chaining: rank 0 chains its block with the fused
+    kernel (f per unit) while rank 1 computes verdicts (a per unit) -- so block 1 is f/a of block 0 --, and each
+    later rank has had (1 + b/a) times longer than the one before it (b per unit = the accept chain), so the blocks
+    grow geometrically.  With equal blocks the later ranks idle after their phase A and rank 0's slow fused block
+    is as long as everyone's; with these shares the makespan is f*n0*(1 + b/a)^(N-1) instead of (f + (N-1)*b)*n/N."""
+    if cost is None or world == 1:
+        return [1.0 / world] * world
+    f, a, b = cost
+    shares = [1.0] + [f / a * (1.0 + b / a) ** (r - 1) for r in range(1, world)]
+    total = sum(shares)
+    return [s / total for s in shares]
+
+
+def split_blocks(weights: Sequence[int], world: int, cost=None) -> list:
+    """Cuts keyframes 0..n-1 into `world` contiguous blocks whose weights (pixels) follow block_shares(world, cost)
+    (cost=None: about equal weight).  Returns [(first, end)] per rank; a rank may get an empty block when there are
+    fewer keyframes than ranks."""
     n = len(weights)
     total = sum(weights)
+    shares = block_shares(world, cost)
     cuts = [0]
     acc = 0
     i = 0
+    upto = 0.0
     for r in range(1, world):
-        want = total * r / world
+        upto += shares[r - 1]
+        want = total * upto
         while i < n and acc + weights[i] / 2 <= want:
             acc += weights[i]
             i += 1
@@ -101,12 +126,13 @@ class RankPlan:
         return (self.local[self.first], self.local[self.end - 1] + 1)
 
 
-def plan_sequence(nbrs: Sequence[Sequence[int]], weights: Sequence[int], world: int) -> list:
+def plan_sequence(nbrs: Sequence[Sequence[int]], weights: Sequence[int], world: int, cost=PIPELINE_COST) -> list:
     """Exact split of one keyframe sequence over `world` ranks by contiguous blocks.  Keyframe i marks pixels in
     the masks of its LATER neighbours (earlier masks are never read again): rank q therefore sends rank r > q the
     masks of those keyframes of r's block that a keyframe of q's block names as a neighbour.  Every rank computes
-    the same plan from the same graph."""
-    blocks = split_blocks(weights, world)
+    the same plan from the same graph.  Block sizes follow block_shares(world, cost): small first blocks, so that
+    the chain reaches the later ranks when their verdicts are ready (cost=None: equal blocks)."""
+    blocks = split_blocks(weights, world, cost)
     owner = {}
     for r, (a, b) in enumerate(blocks):
         for g in range(a, b):

@@ -12,10 +12,10 @@ from helpers import both_params
 pytestmark = pytest.mark.gpu
 
 
-def _run_split(frames, gp, world, W, H):
+def _run_split(frames, gp, world, W, H, cost=dist_fusion.PIPELINE_COST):
     import torch
     nbrs = [f["nbrs"] for f in frames]
-    plans = dist_fusion.plan_sequence(nbrs, [W * H] * len(frames), world)
+    plans = dist_fusion.plan_sequence(nbrs, [W * H] * len(frames), world, cost)
     ctxs, mail = [], {}
     for r, plan in enumerate(plans):
         ctx = fusion.FusionContext(gp)
@@ -69,8 +69,9 @@ def _exchange(ctxs, world):
     return oracle.sort_by_key(xyz, bgr, key, tag)
 
 
-@pytest.mark.parametrize("world,closure", [(2, False), (3, True), (5, False)])
-def test_block_split_of_one_sequence_equals_single_process(world, closure):
+@pytest.mark.parametrize("world,closure,cost", [(2, False, dist_fusion.PIPELINE_COST), (3, True, None),
+                                                (5, False, dist_fusion.PIPELINE_COST), (4, True, (10.0, 40.0, 30.0))])
+def test_block_split_of_one_sequence_equals_single_process(world, closure, cost):
     W, H = 96, 72
     seq = synth.make_sequence(41, W, H, K=(78.75, 78.75, 47.5, 35.5), window=3, yaw_step_deg=2.0)
     frames = seq.frame_dicts()
@@ -79,7 +80,7 @@ def test_block_split_of_one_sequence_equals_single_process(world, closure):
     assert len(dist_fusion.components([f["nbrs"] for f in frames])) == 1
     op, gp = both_params(voxel_size=20.0, T_dist=500.0)
     want = oracle.fuse(frames, op)
-    plans, ctxs = _run_split(frames, gp, world, W, H)
+    plans, ctxs = _run_split(frames, gp, world, W, H, cost)
     stats = [c.stats() for c in ctxs]
     for k in ("n_px", "n_gather", "n_acc", "n_hit"):
         assert sum(s[k] for s in stats) == want.counters[k], k

@@ -73,7 +73,7 @@ def _local_frames(frames, plan):
 def test_plan_covers_every_keyframe_once_and_names_the_mask_traffic():
     frames = _sequence(11, window=3, closure=True)
     nbrs = [f["nbrs"] for f in frames]
-    plans = dist_fusion.plan_sequence(nbrs, [48 * 36] * 11, 3)
+    plans = dist_fusion.plan_sequence(nbrs, [48 * 36] * 11, 3, cost=None)
     assert [p.first for p in plans] == [0, 4, 7] and plans[-1].end == 11
     assert sum(p.end - p.first for p in plans) == 11
     for r, p in enumerate(plans):
@@ -84,6 +84,39 @@ def test_plan_covers_every_keyframe_once_and_names_the_mask_traffic():
             assert t > r and plans[t].recvs[r] == fr and all(plans[t].first <= g < plans[t].end for g in fr)
     assert 10 in plans[0].sends[2]                     # the long edge: rank 0 marks rank 2's keyframe directly
     assert dist_fusion.plan_sequence(nbrs, [1] * 11, 1)[0].sends == {}
+
+
+def test_pipelined_block_shares():
+    """Default block sizes: rank r's verdicts (phase A) are ready just when rank r-1 stops chaining, so the blocks
+    grow along the ranks; the modelled makespan beats equal blocks, and any cost gives a valid cover."""
+    f, a, b = dist_fusion.PIPELINE_COST
+
+    def makespan(blocks):
+        t = f * (blocks[0][1] - blocks[0][0])
+        for first, end in blocks[1:]:
+            t = max(t, a * (end - first)) + b * (end - first)
+        return t
+
+    for world in (2, 3, 4, 8):
+        shares = dist_fusion.block_shares(world)
+        assert abs(sum(shares) - 1.0) < 1e-12 and all(s > 0 for s in shares)
+        assert all(shares[r + 1] > shares[r] for r in range(1, world - 1))
+        blocks = dist_fusion.split_blocks([921600] * 2000, world, dist_fusion.PIPELINE_COST)
+        assert blocks[0][0] == 0 and blocks[-1][1] == 2000
+        assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+        equal = dist_fusion.split_blocks([921600] * 2000, world)
+        assert max(e - s for s, e in equal) - min(e - s for s, e in equal) <= 1
+        assert makespan(blocks) < makespan(equal)
+        # no rank waits for its own phase A: it is done when the chain arrives
+        t = f * (blocks[0][1] - blocks[0][0])
+        for first, end in blocks[1:]:
+            assert a * (end - first) <= t * 1.02
+            t += b * (end - first)
+    assert dist_fusion.block_shares(1) == [1.0]
+    assert dist_fusion.block_shares(4, None) == [0.25] * 4
+    # more ranks than keyframes: empty blocks are allowed, the cover stays exact
+    blocks = dist_fusion.split_blocks([1] * 3, 8, dist_fusion.PIPELINE_COST)
+    assert blocks[0][0] == 0 and blocks[-1][1] == 3 and sum(e - s for s, e in blocks) == 3
 
 
 def test_blockwise_oracle_equals_the_whole_oracle():
