@@ -37,3 +37,9 @@ for k in table_group_kernel finalize_kernel; do
   if [ -n "$nv" ] && [ "$nv" -gt 32 ]; then echo "build.sh: $k uses $nv VGPRs (> 32)" >&2; exit 1; fi
 done
 cp build/libsfm_fusion.so sfm_amd/lib/libsfm_fusion.so
+# the same library with operand checks inside the shared-reciprocal divisions (tests/test_gpu_div_checked.py);
+# its kernels are slower and are never loaded by the product
+mkdir -p build/checked
+hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None -fPIC -std=c++17 \
+  -DSFM_DIV_CHECKED=1 -c sfm_amd/csrc/fusion_capi.hip -o build/checked/fusion_capi.o
+hipcc --offload-arch=gfx950 -fPIC -shared build/checked/fusion_capi.o build/cloud_sort.o -o sfm_amd/lib/libsfm_fusion_checked.so

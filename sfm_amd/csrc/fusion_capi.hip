@@ -535,6 +535,19 @@ int build_layout(sfm_fusion_ctx *c)
     return SFM_OK;
 }
 
+// Test hook of the div-checked build only (libsfm_fusion_checked.so): SFM_CHAIN_DIV_TRUST=1 skips the host-side operand
+// bound, so that the kernels' own checks are what catches an operand outside the shared divisions' range.  The product
+// build has no such switch: there the host-side bound is the only guard and cannot be turned off.
+static inline bool div_trust()
+{
+#if SFM_DIV_CHECKED
+    static const bool on = std::getenv("SFM_CHAIN_DIV_TRUST") && std::atoi(std::getenv("SFM_CHAIN_DIV_TRUST")) != 0;
+    return on;
+#else
+    return false;
+#endif
+}
+
 // One attempt with fixed capacities.  table_cap is a power of two.
 int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t out_cap, uint32_t *err_bits)
 {
@@ -633,7 +646,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     for (size_t i = 0; use_chain && i < n; i++)
         if (c->frames[i].n_filtered > c->chain_items) use_chain = false;
     // ... and its unchecked shared-reciprocal divisions need operands in their range (chain_div_ok)
-    for (size_t i = 0; use_chain && i < n; i++)
+    for (size_t i = 0; use_chain && i < n && !div_trust(); i++)
         if (!chain_div_ok(a.P, c->frames[i].K, c->frames[i].W, c->frames[i].H, c->h_frames[i].Twk, c->h_frames[i].Tkw))
             use_chain = false;
     // with the verdicts of sfm_fusion_precompute the chain is accept_chain_kernel: no LDS slots, no divisions -- all it
@@ -1387,7 +1400,7 @@ int sfm_fusion_precompute(sfm_fusion_ctx *c)
     const DevParams P = make_dev_params(c);
     // the shared-reciprocal divisions need operands in their range, for the keyframe and for its neighbours
     bool shared = true;
-    for (size_t i = 0; shared && i < n; i++)
+    for (size_t i = 0; shared && i < n && !div_trust(); i++)
         shared = chain_div_ok(P, c->frames[i].K, c->frames[i].W, c->frames[i].H, c->h_frames[i].Twk, c->h_frames[i].Tkw);
     // arena: per active keyframe info u32[P] | rec 32 B [P] | hits u32 [n_later][P], each 256-byte aligned
     auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
@@ -1783,6 +1796,13 @@ int sfm_fusion_get_frame_counts(sfm_fusion_ctx *c, uint64_t *before, uint64_t *a
 
 const char *sfm_fusion_last_error(sfm_fusion_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
 
-const char *sfm_fusion_version(void) { return "sfm_fusion 0.2 (gfx950)"; }
+const char *sfm_fusion_version(void)
+{
+#if SFM_DIV_CHECKED
+    return "sfm_fusion 0.2 (gfx950) div-checked";
+#else
+    return "sfm_fusion 0.2 (gfx950)";
+#endif
+}
 
 }  // extern "C"

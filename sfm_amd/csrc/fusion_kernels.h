@@ -166,6 +166,13 @@ __device__ __forceinline__ bool div_operand_bad(double x)
 }
 
 enum DivMode { kDivPlain, kDivShared, kDivSharedChecked };
+// -DSFM_DIV_CHECKED=1 (build.sh: libsfm_fusion_checked.so, loaded by tests/test_gpu_div_checked.py only): the kernels'
+// shared divisions check their operands and raise kErrDivRange, which the host counts as a chain fallback -- the
+// test that the host-side bound (chain_div_ok) never lets an operand outside the range through
+#ifndef SFM_DIV_CHECKED
+#define SFM_DIV_CHECKED 0
+#endif
+constexpr DivMode kDivSharedMode = SFM_DIV_CHECKED ? kDivSharedChecked : kDivShared;
 template <DivMode MODE>
 __device__ __forceinline__ void div_pair(double n0, double n1, double d, double &q0, double &q1, bool &bad)
 {
@@ -195,7 +202,7 @@ __device__ __forceinline__ double cov_trace_vals(const DevParams &P, int u, int 
     const double dd = e23.x;
     double J02, J12;
     // shared: sfm_fusion_run has checked the table's range of disparity^2 and of the numerators (chain_div_ok)
-    div_pair<SHARED ? kDivShared : kDivPlain>((double)(-u) * P.base_line, (double)(-v) * P.base_line, dd, J02, J12, bad);
+    div_pair<SHARED ? kDivSharedMode : kDivPlain>((double)(-u) * P.base_line, (double)(-v) * P.base_line, dd, J02, J12, bad);
     const double P00 = e01.x + (J02 * P.S2) * J02;
     const double P11 = e01.y + (J12 * P.S2) * J12;
     return P00 + (P11 + e23.y);
@@ -541,7 +548,7 @@ __device__ __forceinline__ ObsProj obs_project(const FrameDev &L, double pwx, do
     double xz, yz;
     // shared: sfm_fusion_run has bounded the poses and intrinsics so that cx_, cy_, cz_ are zero or within
     // div_pair's range (chain_div_ok); a check here costs more than the shared reciprocal saves
-    div_pair<SHARED ? kDivShared : kDivPlain>(cx_, cy_, cz_, xz, yz, bad);
+    div_pair<SHARED ? kDivSharedMode : kDivPlain>(cx_, cy_, cz_, xz, yz, bad);
     const double px = xz * L.K[0] + L.K[2];
     const double py = yz * L.K[1] + L.K[3];
     ObsProj r;

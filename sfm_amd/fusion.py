@@ -140,6 +140,11 @@ def default_params(**over) -> FusionParams:
     return p
 
 
+def version() -> str:
+    """The library's version string (the div-checked test build says so here)."""
+    return load_library().sfm_fusion_version().decode()
+
+
 def se3_exp(se3):
     """Sophus::SE3<double>::exp(se3).matrix() and its inverse as (4,4) arrays; se3 = (upsilon, omega)
     (the bundle-adjustment write-back, reference src/map.cpp:321-324)."""
