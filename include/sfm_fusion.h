@@ -219,11 +219,12 @@ int sfm_fusion_set_active_range(sfm_fusion_ctx *ctx, uint32_t first, uint32_t en
 /* Optional, for a rank that waits for its predecessors' masks: everything process_pixel computes except its first
  * test, the visibility mask (:100), is independent of the masks -- the covariance gate (:136-140), geometric_check
  * (:177-234), the pixels it would mark (:152-154), the fused point (:157-165).  This call computes that for every
- * pixel of the active keyframes (asynchronously, on the ctx's stream; 34 + 4 * later-neighbours bytes per pixel of
+ * pixel of the active keyframes (asynchronously, on the ctx's stream; 36 + 4 * later-neighbours bytes per pixel of
  * device memory); the sfm_fusion_run calls that follow only read masks, accept, mark and emit, keyframe after
  * keyframe.  Same cloud, same counts.  It re-observes every pixel, not only those the masks leave (about four
  * times the arithmetic): worth it only where it overlaps another rank's chain.  The verdicts stay valid until
- * keyframes, neighbours or the active range change.  SFM_E_UNSUPPORTED where the chain kernel cannot run. */
+ * keyframes, neighbours or the active range change.  Where the device-wide barrier is unavailable the runs that follow
+ * launch the accept step keyframe by keyframe instead. */
 int sfm_fusion_precompute(sfm_fusion_ctx *ctx);
 /* ORs masks into the state the next runs start from: keyframes [first, first+count), W*H bytes each, packed back
  * to back, device memory.  Dropped by set_active_range, add_keyframe, set_neighbors and clear_imported_masks. */
