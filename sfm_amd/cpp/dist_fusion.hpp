@@ -139,14 +139,19 @@ public:
         const RankPlan plan = plan_sequence(nb, px, world_)[rank_];
 
         sfm_fusion_ctx *ctx = nullptr;
+        struct Guard {  // the ctx and its stream go on every way out, exceptions included
+            sfm_fusion_ctx *&ctx;
+            hipStream_t &stream;
+            ~Guard()
+            {
+                if (ctx) sfm_fusion_destroy(ctx);
+                if (stream) (void)hipStreamDestroy(stream);
+            }
+        } guard{ctx, stream};
         if (sfm_fusion_create(&params_, device_, stream, &ctx) != SFM_OK)
             throw std::runtime_error("sfm_fusion_create failed (no HIP device?)");
         auto check = [&](int rc) {
-            if (rc != SFM_OK) {
-                const std::string msg = sfm_fusion_last_error(ctx);
-                sfm_fusion_destroy(ctx);
-                throw std::runtime_error("sfm_fusion: " + msg);
-            }
+            if (rc != SFM_OK) throw std::runtime_error(std::string("sfm_fusion: ") + sfm_fusion_last_error(ctx));
         };
         std::vector<std::uint32_t> global_order;
         for (std::size_t g : plan.frames) {
@@ -242,8 +247,6 @@ public:
         c.xyz.resize(3 * n); c.bgr.resize(3 * n); c.key.resize(3 * n); c.tag.resize(n);
         check(sfm_fusion_read_points(ctx, c.xyz.data(), c.bgr.data(), c.key.data(), c.tag.data()));
         check(sfm_fusion_get_stats(ctx, &stats_));
-        sfm_fusion_destroy(ctx);
-        (void)hipStreamDestroy(stream);
         return c;
     }
 
