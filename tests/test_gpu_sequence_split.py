@@ -12,10 +12,12 @@ from helpers import both_params
 pytestmark = pytest.mark.gpu
 
 
-def _run_split(frames, gp, world, W, H, cost=dist_fusion.PIPELINE_COST):
+def _run_split(frames, gp, world, W=None, H=None, cost=dist_fusion.PIPELINE_COST):
+    """W, H None: every keyframe has its own size (the mask buffers are packed back to back)."""
     import torch
     nbrs = [f["nbrs"] for f in frames]
-    plans = dist_fusion.plan_sequence(nbrs, [W * H] * len(frames), world, cost)
+    px = [f["depth"].shape[0] * f["depth"].shape[1] for f in frames]
+    plans = dist_fusion.plan_sequence(nbrs, px, world, cost)
     ctxs, mail = [], {}
     for r, plan in enumerate(plans):
         ctx = fusion.FusionContext(gp)
@@ -30,15 +32,17 @@ def _run_split(frames, gp, world, W, H, cost=dist_fusion.PIPELINE_COST):
             buf = mail[(q, r)]
             off = 0
             for first, count in dist_fusion._runs([plan.local[g] for g in fr]):
-                ctx.import_masks(first, count, buf.data_ptr() + off, count * W * H)
-                off += count * W * H
+                nb = sum(px[plan.frames[i]] for i in range(first, first + count))
+                ctx.import_masks(first, count, buf.data_ptr() + off, nb)
+                off += nb
         ctx.run()
         for t, fr in plan.sends.items():
-            buf = torch.empty(len(fr) * W * H, dtype=torch.uint8, device="cuda")
+            buf = torch.empty(max(1, sum(px[g] for g in fr)), dtype=torch.uint8, device="cuda")
             off = 0
             for first, count in dist_fusion._runs([plan.local[g] for g in fr]):
-                ctx.export_masks(first, count, buf.data_ptr() + off, count * W * H)
-                off += count * W * H
+                nb = sum(px[plan.frames[i]] for i in range(first, first + count))
+                ctx.export_masks(first, count, buf.data_ptr() + off, nb)
+                off += nb
             mail[(r, t)] = buf
         ctxs.append(ctx)
     return plans, ctxs
@@ -93,6 +97,26 @@ def test_block_split_of_one_sequence_equals_single_process(world, closure, cost)
         fb[plan.first:plan.end] = b[a0:a1]
         fa[plan.first:plan.end] = a[a0:a1]
     assert np.array_equal(fb, want.frame_before) and np.array_equal(fa, want.frame_after)
+    xyz, bgr, key, tag = _exchange(ctxs, world)
+    assert np.array_equal(key, want.key) and np.array_equal(tag, want.tag)
+    assert np.array_equal(bgr, want.bgr) and np.array_equal(xyz.view(np.uint64), want.xyz.view(np.uint64))
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.parametrize("seed,world", [(1, 2), (4, 3), (8, 2), (12, 3), (17, 4), (22, 2), (33, 3)])
+def test_block_split_of_random_scenes(seed, world):
+    """The random scenes of tests/test_gpu_fuzz.py -- per-keyframe image sizes and intrinsics, arbitrary and asymmetric
+    neighbour lists (edges that jump over whole blocks, keyframes that name a neighbour which does not name them) --
+    cut into blocks: the union is the oracle's cloud."""
+    from test_gpu_fuzz import random_scene
+    frames, params = random_scene(seed)
+    op, gp = both_params(**params)
+    want = oracle.fuse(frames, op)
+    plans, ctxs = _run_split(frames, gp, world)
+    stats = [c.stats() for c in ctxs]
+    for k in ("n_px", "n_gather", "n_acc", "n_hit"):
+        assert sum(s[k] for s in stats) == want.counters[k], k
     xyz, bgr, key, tag = _exchange(ctxs, world)
     assert np.array_equal(key, want.key) and np.array_equal(tag, want.tag)
     assert np.array_equal(bgr, want.bgr) and np.array_equal(xyz.view(np.uint64), want.xyz.view(np.uint64))
