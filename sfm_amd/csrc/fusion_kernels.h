@@ -1187,10 +1187,10 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
             uint32_t pos[kChainSegs], mv[kChainSegs];
 #pragma unroll
             for (int u = 0; u < kChainSegs; u++) {
-                // only lanes with a candidate pixel ask: a default address would make one mask byte the target
-                // of every idle lane of every workgroup, and these loads go past the L2 to the memory side
-                mv[u] = 255u;
-                if (pre.cand[u]) mv[u] = mask_load_coherent(F.mask + pre.pixel[u]);
+                // Unconditional: every lane with a pixel in the image asks for its own byte, candidate or not (a branch
+                // around the load costs 1.7 % of a C2 run; one default address for all idle lanes would make a single
+                // mask byte the target of every workgroup, and these loads go past the L2 to the memory side).
+                mv[u] = mask_load_coherent(F.mask + (pre.pixel[u] < (uint32_t)F.W * (uint32_t)F.H ? pre.pixel[u] : 0u));
             }
 #pragma unroll
             for (int u = 0; u < kChainSegs; u++) {
