@@ -28,6 +28,17 @@
 #else
 #define SFM_OBSERVE_OCC
 #endif
+#ifndef SFM_FIN_TOP
+#define SFM_FIN_TOP 0  // fuse_chain_kernel: 1 = chunks are fused by the last waves of the workgroup instead of the first (measured: +1.4 % on C2)
+#endif
+#ifndef SFM_TABLE_MARK_CAS
+// table_group_kernel's per-keyframe mark: 1 = plain read + compare-and-swap loop (round 2), 0 = mark read with key and tag,
+// idempotent atomicMin reset + atomicAnd, no CAS, no retry.  Both are bit-exact on the whole GPU suite;
+// measured on C2 (profiles/r03_ab_table_mark.txt) the CAS-free kernel is the FASTER kernel and the SLOWER run (7.78 against
+// 7.62 ms at 16 workgroups per shard, 7.74 at its best grid of 12): what it saves is a round trip per entry, what slows
+// the chain beside it is its traffic per microsecond, which goes up.
+#define SFM_TABLE_MARK_CAS 1
+#endif
 #ifndef SFM_STAMPS
 #define SFM_STAMPS 0  // diagnostic build only (tools/chain_stamps.py): adds fuse_chain_kernel_stamps, thread-0 phase timestamps of one launch
 #endif
@@ -173,6 +184,22 @@ enum DivMode { kDivPlain, kDivShared, kDivSharedChecked };
 #define SFM_DIV_CHECKED 0
 #endif
 constexpr DivMode kDivSharedMode = SFM_DIV_CHECKED ? kDivSharedChecked : kDivShared;
+// the part of a shared division that depends on the denominator alone: v_rcp_f64 and two Newton steps
+__device__ __forceinline__ double div_recip(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+// ... and one quotient from it: n/d for operands inside the range (r = div_recip(d))
+__device__ __forceinline__ double div_with(double n, double d, double r)
+{
+    const double t = n * r;
+    return __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-d, t, n), r, t), d, n);
+}
+
 template <DivMode MODE>
 __device__ __forceinline__ void div_pair(double n0, double n1, double d, double &q0, double &q1, bool &bad)
 {
@@ -183,14 +210,39 @@ __device__ __forceinline__ void div_pair(double n0, double n1, double d, double 
     }
     // kDivShared: the caller's operands were validated elsewhere (host, sfm_fusion_run)
     if (MODE == kDivSharedChecked) bad = bad || div_operand_bad(d) || div_operand_bad(n0) || div_operand_bad(n1);
-    double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    const double t0 = n0 * r, t1 = n1 * r;
-    q0 = __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-d, t0, n0), r, t0), d, n0);
-    q1 = __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-d, t1, n1), r, t1), d, n1);
+    const double r = div_recip(d);
+    q0 = div_with(n0, d, r);
+    q1 = div_with(n1, d, r);
+}
+
+// n0/d, n1/d, n2/d, bit for bit three IEEE divisions, for ANY operands: the wave looks at its operands and takes the
+// shared-reciprocal form only when every active lane's are inside its range, else it divides plainly.  For the two
+// triples of the fusion step -- the weighted sums over their total (:164) and the fused coordinates over the voxel
+// size (:270-274) -- whose operands (sums that may cancel) have no bound that the host could check ahead.
+// SHARED = false: three plain divisions.  Measured on C2 (tools/ab_bench.sh, profiles/r03_ab_fusion_step.txt): in
+// fuse_chain_kernel the shared form is 3.3 % SLOWER (the fusion step is a dependent chain on a few waves, not an issue
+// bound: the operand checks lengthen it), so the chain keeps plain divisions there.
+#ifndef SFM_DIV_TRIPLE_CHAIN
+#define SFM_DIV_TRIPLE_CHAIN 0
+#endif
+#ifndef SFM_DIV_TRIPLE_VERDICT
+#define SFM_DIV_TRIPLE_VERDICT 1
+#endif
+template <bool SHARED>
+__device__ __forceinline__ void div_triple(double n0, double n1, double n2, double d, bool active, double &q0, double &q1,
+                                           double &q2)
+{
+    const bool bad = SHARED && active && (div_operand_bad(d) || div_operand_bad(n0) || div_operand_bad(n1) || div_operand_bad(n2));
+    if (!SHARED || __ballot(bad) != 0ull) {  // wave-uniform
+        q0 = n0 / d;
+        q1 = n1 / d;
+        q2 = n2 / d;
+        return;
+    }
+    const double r = div_recip(d);
+    q0 = div_with(n0, d, r);
+    q1 = div_with(n1, d, r);
+    q2 = div_with(n2, d, r);
 }
 
 // Same value as cov_trace(), bit for bit, with the four divisions that depend on the depth
@@ -276,6 +328,34 @@ __device__ __forceinline__ bool axis_code_of(double coord, double vs, unsigned l
     return (q != q) || t >= 18446744073709551616.0 || t <= -9223372036854775808.0;
 }
 
+// static_cast<size_t>(q), q = coord / voxel_size, as x86-64 evaluates it, returned
+// as a signed 64-bit index; INT64_MIN stands for the 0x8000000000000000 "indefinite" key.
+__device__ __forceinline__ long long voxel_index_q(double q)
+{
+    if (q != q) return INT64_MIN;
+    const double t = trunc(q);
+    if (t >= -9223372036854775808.0 && t < 9223372036854775808.0) return (long long)t;
+    if (t >= 9223372036854775808.0 && t < 18446744073709551616.0)
+        return (long long)(unsigned long long)t;
+    return INT64_MIN;
+}
+
+// Default packing: 21-bit two's-complement code of static_cast<size_t>(q); 0x100000 is reserved for the
+// indefinite index (NaN, >= 2^64, <= -2^63 -- voxel_index_q's INT64_MIN cases).  32-bit conversions only.
+// Returns false when the index does not fit.
+__device__ __forceinline__ bool axis_code_of_q(double q, unsigned long long &code)
+{
+    double t = trunc(q);
+    // [2^63, 2^64) converts to the size_t bits of the negative index t - 2^64 (exact subtraction)
+    if (t >= 9223372036854775808.0 && t < 18446744073709551616.0) t = t - 18446744073709551616.0;
+    if (t >= -1048575.0 && t <= 1048575.0) {
+        code = (unsigned long long)(unsigned int)(int)t & 0x1FFFFFull;
+        return true;
+    }
+    code = 0x100000ull;
+    return (q != q) || t >= 18446744073709551616.0 || t <= -9223372036854775808.0;
+}
+
 // General packing (DevParams::key): code of index k (INT64_MIN = indefinite) within [lo, hi]
 __host__ __device__ inline bool axis_code_range(long long k, long long lo, long long hi, unsigned long long &code)
 {
@@ -303,8 +383,38 @@ __host__ __device__ inline unsigned long long axis_code_count(long long lo, long
     return (unsigned long long)(hi - lo) + 2ull;  // (lo <= hi; callers keep hi - lo < 2^53)
 }
 
-// The packed key of a fused point.  false: an index does not fit the run's packing (the caller raises kErrKeyRange),
-// or this is a range-scan run (every point is "unfit" and leaves its indices in key_scan_out).
+// The packed key of a fused point from its three quotients coord / voxel_size (:270-274).  false: an index does not
+// fit the run's packing (the caller raises kErrKeyRange), or this is a range-scan run (every point is "unfit" and
+// leaves its indices in key_scan_out).
+__device__ __forceinline__ bool pack_voxel_key_q(const DevParams &P, double qx, double qy, double qz, unsigned long long &key)
+{
+    unsigned long long c0, c1, c2;
+    if (!P.key_wide && !P.key_scan) {  // wave-uniform
+        const int fits = (int)axis_code_of_q(qx, c0) & (int)axis_code_of_q(qy, c1) & (int)axis_code_of_q(qz, c2);
+        key = (c0 << 42) | (c1 << 21) | c2;
+        return fits != 0;
+    }
+    const long long i0 = voxel_index_q(qx), i1 = voxel_index_q(qy), i2 = voxel_index_q(qz);
+    if (P.key_scan) {
+        KeyRangeDev *r = P.key_scan_out + (blockIdx.x + threadIdx.x / 64u) % kStatShards;
+        const long long v[3] = {i0, i1, i2};
+        for (int a = 0; a < 3; a++) {
+            if (v[a] == INT64_MIN) continue;
+            // (the plain reads may be stale: then an atomic too many is issued, never one too few)
+            if (v[a] < r->lo[a]) __hip_atomic_fetch_min(&r->lo[a], v[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v[a] > r->hi[a]) __hip_atomic_fetch_max(&r->hi[a], v[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        key = 0;
+        return false;
+    }
+    const int fits = (int)axis_code_range(i0, P.key.lo[0], P.key.hi[0], c0) & (int)axis_code_range(i1, P.key.lo[1], P.key.hi[1], c1) &
+                     (int)axis_code_range(i2, P.key.lo[2], P.key.hi[2], c2);
+    key = (c0 << (P.key_bits[1] + P.key_bits[2])) | (c1 << P.key_bits[2]) | c2;
+    return fits != 0;
+}
+
+// ... from the coordinates, with plain divisions (round 2's form, kept verbatim: fuse_chain_kernel's code generation
+// is sensitive to it)
 __device__ __forceinline__ bool pack_voxel_key(const DevParams &P, double fx, double fy, double fz, unsigned long long &key)
 {
     unsigned long long c0, c1, c2;
@@ -333,12 +443,30 @@ __device__ __forceinline__ bool pack_voxel_key(const DevParams &P, double fx, do
     return fits != 0;
 }
 
+
 // Every NaN the reference can produce on this path is x86's "real indefinite" (sign bit set, quiet,
 // zero payload: SSE2 returns it for 0*inf, inf-inf, inf/inf, and propagates it unchanged); gfx950
 // generates the positive quiet NaN.  The fused coordinates leave the kernels with the reference's bits.
 __device__ __forceinline__ double x86_nan(double v)
 {
     return v != v ? __longlong_as_double((long long)0xFFF8000000000000ull) : v;
+}
+
+// The tail of process_pixel for one accepted pixel in the chain kernels: the fused point (:164) and its packed voxel
+// key (:270-274), six divisions as two shared-reciprocal triples.  `ok` = the lane holds an accepted pixel.
+template <bool SHARED>
+__device__ __forceinline__ bool fuse_point_and_key(const DevParams &P, double wx, double wy, double wz, double total, bool ok,
+                                                   double &fx, double &fy, double &fz, unsigned long long &key)
+{
+    div_triple<SHARED>(wx, wy, wz, total, ok, fx, fy, fz);
+    fx = x86_nan(fx); fy = x86_nan(fy); fz = x86_nan(fz);
+    double qx, qy, qz;
+    div_triple<SHARED>(fx, fy, fz, P.voxel_size, ok, qx, qy, qz);
+    if (!ok) {  // (a range-scan run records the indices of every lane that packs)
+        key = 0;
+        return false;
+    }
+    return pack_voxel_key_q(P, qx, qy, qz, key);
 }
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
@@ -389,6 +517,12 @@ __device__ __forceinline__ void mask_store_coherent(uint8_t *p)
 __device__ __forceinline__ unsigned long long lanemask_lt()
 {
     return (1ull << lane_id()) - 1ull;
+}
+
+// number of set bits of m below this lane (v_mbcnt: no lane mask kept in registers)
+__device__ __forceinline__ unsigned lane_rank(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
 __device__ __forceinline__ unsigned wave_sum(unsigned v)
@@ -1228,9 +1362,13 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                 for (uint32_t c0 = 0; c0 < chunks; c0 += R) {
                     const uint32_t rc = min(R, chunks - c0);
                     const uint32_t items = rc * K;
-                    // wave w finishes chunk c0+w (step C)
-                    const bool fin = w < rc;
-                    const uint32_t cf = c0 + w;
+                    // The round's chunks are finished (step C's fusion) by the LAST waves, chunk c0+j by wave 15-j: wave 0
+                    // waits for the barrier arrival's atomic to return, and the first waves have the second segment of
+                    // the next keyframe's preparation and (K dividing 16) one item more in step B -- the workgroup is
+                    // as late for the next keyframe as its busiest wave
+                    const unsigned wf = SFM_FIN_TOP ? (unsigned)kChainWaves - 1u - w : w;
+                    const bool fin = wf < rc;
+                    const uint32_t cf = c0 + wf;
                     const uint32_t n_in = fin ? min(n - cf * kWave, (uint32_t)kWave) : 0u;
                     const bool actf = lane < n_in;
                     unsigned int *cnt_now = s_cnt + (round_no & 1u) * (kChainWaves * kWave);
@@ -1275,8 +1413,8 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                     if (fin) {
                         // (the colour, :170, is read by finalize_kernel for the voxels' winners only)
                         const uint32_t pixf = s_spix[min(cf * kWave + lane, (uint32_t)kChainSurv - 1)];
-                        const uint32_t it0 = w * K;
-                        const unsigned pc = cnt_now[w * kWave + lane];
+                        const uint32_t it0 = wf * K;
+                        const unsigned pc = cnt_now[wf * kWave + lane];
                         const unsigned n_obs = pc & 0xFFFFu, n_close = pc >> 16;
                         bool ok = actf && n_obs >= 1;                                        // :218
                         if ((double)n_close < (double)n_obs * P.close_frac) ok = false;      // :229
@@ -1305,6 +1443,15 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                         SFM_CSTAMP(10);
                         unsigned long long key = 0, tag = kEmpty;
                         double fx = 0, fy = 0, fz = 0;
+#if SFM_DIV_TRIPLE_CHAIN
+                        if (__ballot(ok) != 0ull) {  // wave-uniform: the shared-reciprocal triples look at the whole wave's operands
+                            const bool fits = fuse_point_and_key<true>(P, wx, wy, wz, total, ok, fx, fy, fz, key);  // :164, :270-274
+                            if (ok) {
+                                if (fits) tag = ((unsigned long long)F.order << 32) | pixf;
+                                else err |= kErrKeyRange;
+                            }
+                        }
+#else
                         if (ok) {
                             fx = x86_nan(wx / total); fy = x86_nan(wy / total); fz = x86_nan(wz / total);               // :164
                             if (pack_voxel_key(P, fx, fy, fz, key)) {
@@ -1313,6 +1460,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                                 err |= kErrKeyRange;
                             }
                         }
+#endif
                         SFM_CSTAMP(11);
                         if (actf) {
                             const unsigned long long rel = *reinterpret_cast<unsigned long long *>(s_misc + 2) + cf * kWave + lane;
@@ -1505,13 +1653,15 @@ __global__ __launch_bounds__(256) void verdict_kernel(const FrameDev *__restrict
     bool ok = cand && n_obs >= 1;                                        // :218
     if ((double)n_close < (double)n_obs * P.close_frac) ok = false;      // :229
     uint32_t info = cand ? (kVCand | (n_obs << 12) | n_vis) : 0u;
-    if (ok) {
-        const double fx = x86_nan(wx / total), fy = x86_nan(wy / total), fz = x86_nan(wz / total);  // :164
+    if (__ballot(ok) != 0ull) {  // wave-uniform
+        double fx, fy, fz;
         VerdictRec r;
-        const bool fits = pack_voxel_key(P, fx, fy, fz, r.key);
-        info |= fits ? kVOk : (kVOk | kVKeyRange);
-        r.x = fx; r.y = fy; r.z = fz;
-        V.rec[pix] = r;
+        const bool fits = fuse_point_and_key<SHARED && SFM_DIV_TRIPLE_VERDICT != 0>(P, wx, wy, wz, total, ok, fx, fy, fz, r.key);  // :164, :270-274
+        if (ok) {
+            info |= fits ? kVOk : (kVOk | kVKeyRange);
+            r.x = fx; r.y = fy; r.z = fz;
+            V.rec[pix] = r;
+        }
     }
     if (in) V.info[pix] = info;
     if (__ballot(bad) != 0ull && lane_id() == 0) atomicOr(&stat[blockIdx.x % kStatShards].err, kErrDivRange);
@@ -1795,7 +1945,11 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
     unsigned long long end = a.list.group_end[(size_t)a.group * kListShards * 8 + shard * 8];
     if (end > a.list.shard_cap) end = a.list.shard_cap;
     const unsigned long long base = (unsigned long long)shard * a.list.shard_cap;
+#if SFM_TABLE_MARK_CAS
     const unsigned long long want_hi = (unsigned long long)a.group + 1ull;
+#else
+    const uint32_t inv_hi = ~(a.group + 1u);
+#endif
     const unsigned lane = lane_id();
     unsigned long long cbase = 0;  // wave-uniform: this wave's chunk of the candidate list
     unsigned cleft = 0;
@@ -1816,8 +1970,15 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
             unsigned probes = 0;
             bool found = false;
             unsigned long long seen = kEmpty;  // the slot's tag as last seen
+#if !SFM_TABLE_MARK_CAS
+            uint32_t mark_st = 1u;  // ... and of its (inverted) mark: 2 = the word is this group's, 1 = this keyframe's bit is still up
+#endif
             for (;;) {
                 const ulonglong2 s01 = *reinterpret_cast<const ulonglong2 *>(a.table + h);  // key and tag in one read
+#if !SFM_TABLE_MARK_CAS
+                const uint2 mk = *reinterpret_cast<const uint2 *>(&a.table[h].mark);       // ... and the mark with them
+                mark_st = (mk.y == inv_hi ? 2u : 0u) | ((mk.x >> fr) & 1u);
+#endif
                 unsigned long long cur = s01.x;
                 seen = s01.y;
                 if (cur == kEmpty) {
@@ -1833,13 +1994,13 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
                 s_err = kErrTableFull;
             } else {
                 if (probes) atomicMax(&s_maxprobe, probes);
-                // the atomicMin and the read of the mark are in flight together
-                unsigned long long prev_tag = seen;
-                if (seen > tag) prev_tag = atomicMin(&a.table[h].tag, tag);
-                unsigned long long old = a.table[h].mark;  // a fresh slot holds kEmpty: no group has that id
                 // Only an entry that was its voxel's smallest tag at this moment can still win:
                 // it goes on the candidate list that finalize_kernel walks.
+                unsigned long long prev_tag = seen;
+                if (seen > tag) prev_tag = atomicMin(&a.table[h].tag, tag);
                 lower = prev_tag > tag;
+#if SFM_TABLE_MARK_CAS
+                unsigned long long old = a.table[h].mark;  // a fresh slot holds kEmpty: no group has that id
                 const unsigned long long bit = 1ull << fr;
                 for (;;) {
                     const bool same = (old >> 32) == want_hi;
@@ -1849,6 +2010,28 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
                     if (prev == old) { atomicAdd(&s_after[fr], 1u); break; }
                     old = prev;
                 }
+#else
+                // The keyframe's "after" count (:120): the first entry of (voxel, keyframe) counts.  The mark is kept
+                // INVERTED, ~((group+1) << 32 | bits of the group's keyframes that touched the voxel): a fresh slot's
+                // all-ones is "no group" and a later group's word is SMALLER, so an atomicMin with (this group, no bit
+                // down) resets an older group's word and leaves this group's alone -- idempotent, nobody waits for it --
+                // and an atomicAnd takes this keyframe's bit down; the value it returns says who was first.  No
+                // compare-and-swap, and no atomic at all for an entry whose bit the slot's first read showed down
+                // (a stale read only shows an older state: then an atomic too many is issued, never one too few).
+                const uint32_t bit = 1u << fr;
+                if (!(mark_st & 2u)) {
+                    unsigned long long reset = ((unsigned long long)inv_hi << 32) | 0xFFFFFFFFull;
+                    asm volatile("" : "+v"(reset));  // formed here: hoisted out of the loop it holds two registers (34 > 32, see build.sh)
+                    (void)__hip_atomic_fetch_min(&a.table[h].mark, reset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mark_st = 3u;
+                }
+                // (the reset and the AND of one lane are two accesses of one thread to one location: they execute in
+                // program order -- coherence per location, which the compiler relies on for every store-then-load of a
+                // thread as well)
+                bool first = false;
+                if (mark_st == 3u) first = ((uint32_t)atomicAnd(&a.table[h].mark, ~(unsigned long long)bit) & bit) != 0u;
+                if (first) atomicAdd(&s_after[fr], 1u);
+#endif
             }
         }
         // candidate append into the wave's chunk
@@ -1863,7 +2046,7 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
                         (unsigned)__builtin_amdgcn_readfirstlane((int)nb);
                 cleft = kCandChunk;
             }
-            if (lower) a.cand[cbase + (unsigned)__popcll(m & lanemask_lt())] = base + begin + r;
+            if (lower) a.cand[cbase + lane_rank(m)] = base + begin + r;
             cbase += cnt;
             cleft -= cnt;
         }
