@@ -39,6 +39,12 @@
 // the chain beside it is its traffic per microsecond, which goes up.
 #define SFM_TABLE_MARK_CAS 1
 #endif
+#ifndef SFM_ACC_PREFETCH_REC
+#define SFM_ACC_PREFETCH_REC 0  // accept_chain_kernel: 1 = every pixel's fused point is read before the barrier opens (measured slower)
+#endif
+#ifndef SFM_DIAG_ACC_NOREC
+#define SFM_DIAG_ACC_NOREC 0    // diagnostic only (wrong cloud): accept_chain_kernel writes tags without reading or writing the fused points
+#endif
 #ifndef SFM_STAMPS
 #define SFM_STAMPS 0  // diagnostic build only (tools/chain_stamps.py): adds fuse_chain_kernel_stamps, thread-0 phase timestamps of one launch
 #endif
@@ -1040,6 +1046,26 @@ __device__ __forceinline__ void chain_arrive(unsigned int *bar, unsigned G, unsi
     }
 }
 
+// chain_arrive in two halves, for a caller with other work to issue under the first atomic's round trip
+__device__ __forceinline__ unsigned chain_arrive_issue(unsigned int *bar)
+{
+    return __hip_atomic_fetch_add(bar + (blockIdx.x % kBarSub) * kBarSubSpace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_arrive_finish(unsigned int *bar, unsigned G, unsigned epoch, unsigned prev)
+{
+    const unsigned s = blockIdx.x % kBarSub;
+    const unsigned members = G / kBarSub + (s < G % kBarSub ? 1u : 0u);
+    if (prev == epoch * members - 1u) {
+        const unsigned subs = G < (unsigned)kBarSub ? G : (unsigned)kBarSub;
+        const unsigned p2 = __hip_atomic_fetch_add(bar + kBarTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p2 == epoch * subs - 1u) {
+#pragma unroll
+            for (int x = 0; x < kBarFlags; x++)
+                __hip_atomic_store(bar + kBarFlagX + x * kBarFlagSpace, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned chain_progress(const unsigned int *bar, unsigned G)
 {
     (void)G;
@@ -1671,9 +1697,19 @@ __global__ __launch_bounds__(256) void verdict_kernel(const FrameDev *__restrict
 // list-boundary machinery of fuse_chain_kernel.  A keyframe is dealt in runs of 64 pixels (one wave, coalesced):
 // run t goes to workgroup t mod G, so that every workgroup samples the whole image -- accepted pixels cluster where
 // the camera sees something new, and the marks of a 1024-pixel tile full of them (4096 one-byte write-through
-// stores from one CU) made the keyframe wait for that one workgroup.  A workgroup takes 64 runs per pass (kAccIter
-// per wave; one list reservation per workgroup and pass).
+// stores from one CU) made the keyframe wait for that one workgroup.
+//
+// Roles (round 3).  Wave 0 is the workgroup's CONTROL wave and touches no pixel: it polls the barrier flag, makes the
+// barrier arrival, scans the pass's per-wave counts and reserves the list space.  Waves 1..15 are DATA waves, kAccIter
+// runs each per pass.  A wave's vector-memory operations complete in issue order, so whatever a wave has in flight
+// stands in front of its next poll or its next acknowledgement wait: in round 2 thread 0's polls queued behind its own
+// wave's twenty prefetch loads and record stores, and every wave's wait for the marks' acknowledgement also waited for
+// the cold record loads issued in front of it.  Now the control wave's queue holds its polls and two atomics only, and a
+// data wave has nothing but its marks (and loads that returned long ago) in flight when it waits; the records of the
+// accepted pixels are read and written behind the arrival.  tools/link_variants_bench.hip measures the same link
+// with no records at all at 4.1 us per keyframe (C2 shape); round 2's kernel took 9.0.
 constexpr int kAccIter = 4;
+constexpr int kAccDataWaves = kChainWaves - 1;
 
 struct AcceptArgs {
     ChainArgs c;                 // f0, f1, group, list, stat, bar, P, abort_all, timeout_ticks (item_cap, stamps unused)
@@ -1688,8 +1724,8 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                                                   const VerdictDev *__restrict__ verdicts,
                                                   uint8_t *const *__restrict__ later_masks, const AcceptArgs &aa)
 {
-    static_assert(kAccIter * kChainWaves == kWave, "one wave scans the pass's per-wave counts");
-    __shared__ unsigned int s_wave[kAccIter * kChainWaves], s_off[kAccIter * kChainWaves];
+    static_assert(kAccIter * kAccDataWaves <= kWave, "one wave scans the pass's per-wave counts");
+    __shared__ unsigned int s_wave[kWave], s_off[kWave];
     __shared__ unsigned int s_go;
     __shared__ unsigned long long s_base;
     const ChainArgs &a = aa.c;
@@ -1699,127 +1735,36 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
     unsigned c_gather = 0, c_hit = 0, err = 0;
     const bool aborted = bar_load(a.abort_all) != 0u;
     if (aborted) err |= kErrBarrier;
-    for (uint32_t f = a.f0; f < a.f1 && !aborted; f++) {
-        const FrameDev &F = frames[f];
-        const VerdictDev &V = verdicts[f - aa.v_first];
-        uint8_t *const *later_mask = later_masks + V.later_begin;
-        const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
-        SFM_CSTAMP(0);
-        const uint32_t runs = F.nbr_count ? (npx + kWave - 1) / kWave : 0u;            // 64-pixel runs of the keyframe
-        const uint32_t mine = (runs + G * kChainWaves - 1) / (G * kChainWaves);         // runs per wave (same for every workgroup)
-        // Neither the verdicts nor the pixels they would mark depend on the masks: the first pass's verdicts and its
-        // stored hit pixels in the first four later neighbours are requested before the barrier opens (dense,
-        // coalesced loads for every pixel of the tile, accepted or not: four times the bytes, none of the latency)
-        // (the loads are unconditional -- a lane without a pixel reads pixel 0, a missing neighbour slot the last
-        // one -- and nothing looks at their values before the barrier: no wait is placed in front of it)
-        // (loads return in order within a wave: thread 0 looks at the barrier flag once BEFORE the prefetch and waits
-        // for that value alone (0.2 us), so that a barrier that is already open -- the last workgroup to arrive, which
-        // every other one waits for -- does not cost the latency of twenty cold loads in front of the first poll)
-        bool open_early = false;
-        if (f > a.f0 && threadIdx.x == 0) {
-            const unsigned early = chain_progress(a.bar, G);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            open_early = early >= f - a.f0;
-        }
-        uint32_t pixv[kAccIter], infov[kAccIter], h[kAccIter][4];
-        bool inv[kAccIter];
-        const uint32_t nl = V.n_later;
-        const uint32_t ql = nl ? nl - 1u : 0u;
-#pragma unroll
-        for (int j = 0; j < kAccIter; j++) {
-            pixv[j] = (((uint32_t)j * kChainWaves + w) * G + b) * kWave + lane;
-            inv[j] = (uint32_t)j < mine && pixv[j] < npx;
-            const uint32_t pa = inv[j] ? pixv[j] : 0u;
-            infov[j] = mine ? (uint32_t)ldg(V.info + pa) : 0u;  // (uniform conditions: an empty keyframe has nothing to read)
-#pragma unroll
-            for (int q = 0; q < 4; q++) h[j][q] = (mine && nl) ? ldg(V.hits + (size_t)min((uint32_t)q, ql) * npx + pa) : kNoHit;
-        }
-        chain_stamp<STAMPS>(a, f, 10);
-        if (f > a.f0) {
-            if (threadIdx.x == 0)
-                s_go = (open_early || chain_wait(a.bar, f - a.f0, G, a.timeout_ticks, a.abort_all)) ? 1u : 0u;
-            __syncthreads();
-            if (s_go == 0u) {  // workgroup-uniform
+    if (threadIdx.x < kWave) s_wave[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_go = 1u;
+    __syncthreads();
+    // The two roles run the same sequence of workgroup barriers -- one per keyframe (B1: the device-wide barrier has
+    // opened), two per pass (B2: every data wave's marks are acknowledged; B3: the pass's list space is known) -- each in
+    // its own code path (the branch is wave-uniform).
+    if (w == 0u) {
+        // ---- control wave
+        for (uint32_t f = a.f0; f < a.f1 && !aborted; f++) {
+            const FrameDev &F = frames[f];
+            const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
+            SFM_CSTAMP(0);
+            const uint32_t runs = F.nbr_count ? (npx + kWave - 1) / kWave : 0u;
+            const uint32_t mine = (runs + G * kAccDataWaves - 1) / (G * kAccDataWaves);
+            // every workgroup arrived after keyframe f-1 (below); its marks are out
+            if (f > a.f0 && lane == 0) s_go = chain_wait(a.bar, f - a.f0, G, a.timeout_ticks, a.abort_all) ? 1u : 0u;
+            __syncthreads();  // B1
+            if (s_go == 0u) {
                 err |= kErrBarrier;
                 break;
             }
-        }
-        SFM_CSTAMP(1);
-        for (uint32_t t0 = 0; t0 < mine || t0 == 0; t0 += kAccIter) {
-            if (t0) {
-#pragma unroll
-                for (int j = 0; j < kAccIter; j++) {
-                    pixv[j] = (((t0 + (uint32_t)j) * kChainWaves + w) * G + b) * kWave + lane;
-                    inv[j] = t0 + (uint32_t)j < mine && pixv[j] < npx;
-                    const uint32_t pa = inv[j] ? pixv[j] : 0u;
-                    infov[j] = (uint32_t)ldg(V.info + pa);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) h[j][q] = nl ? ldg(V.hits + (size_t)min((uint32_t)q, ql) * npx + pa) : kNoHit;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kAccIter; j++) infov[j] = inv[j] ? infov[j] : 0u;
-            // mask == 0 (:100) for the pixels that reach geometric_check; only those lanes ask
-            uint32_t mv[kAccIter];
-#pragma unroll
-            for (int j = 0; j < kAccIter; j++) {
-                mv[j] = 255u;
-                if (infov[j] & kVCand) mv[j] = mask_load_coherent(F.mask + pixv[j]);
-            }
-            bool acc[kAccIter];
-            unsigned pos[kAccIter];
-#pragma unroll
-            for (int j = 0; j < kAccIter; j++) {
-                const bool live = (infov[j] & kVCand) && mv[j] == 0u;
-                acc[j] = live && (infov[j] & kVOk);
-                c_gather += live ? (infov[j] & 0xFFFu) : 0u;
-                c_hit += acc[j] ? ((infov[j] >> 12) & 0xFFFu) : 0u;
-                if (acc[j] && (infov[j] & kVKeyRange)) err |= kErrKeyRange;
-                const unsigned long long m = __ballot(acc[j]);
-                pos[j] = (unsigned)__popcll(m & lanemask_lt());
-                if (lane == 0) s_wave[j * kChainWaves + w] = (unsigned)__popcll(m);
-            }
-            // the marks (:152-154) of the accepted pixels, into the masks of keyframes still to come: the first four
-            // later neighbours from the registers ...
-#pragma unroll
-            for (int j = 0; j < kAccIter; j++)
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit) mask_store_coherent(later_mask[q] + h[j][q]);
-            // ... the others four at a time (unconditional loads: a lane without an accepted pixel reads element 0)
-            for (uint32_t s0 = 4; s0 < nl; s0 += 4) {
-                uint32_t h2[kAccIter][4];
-#pragma unroll
-                for (int j = 0; j < kAccIter; j++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        h2[j][q] = ldg(V.hits + (size_t)min(s0 + (uint32_t)q, nl - 1u) * npx + (acc[j] ? pixv[j] : 0u));
-#pragma unroll
-                for (int j = 0; j < kAccIter; j++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (acc[j] && s0 + (uint32_t)q < nl && h2[j][q] != kNoHit)
-                            mask_store_coherent(later_mask[s0 + q] + h2[j][q]);
-            }
-            // the accepted pixels' fused points: requested now, so that their (cold, scattered) round trip runs under the
-            // wait for the marks' acknowledgement instead of behind the barrier arrival (unconditional loads)
-            VerdictRec rv[kAccIter];
-#pragma unroll
-            for (int j = 0; j < kAccIter; j++) {
-                const VerdictRec *rp = V.rec + (acc[j] ? pixv[j] : 0u);
-                typedef unsigned long long ull2_t __attribute__((ext_vector_type(2)));
-                const ull2_t k0 = *(const __attribute__((address_space(1))) ull2_t *)rp;
-                const ull2_t k1 = *((const __attribute__((address_space(1))) ull2_t *)rp + 1);
-                rv[j].key = k0.x;
-                rv[j].x = __longlong_as_double((long long)k0.y);
-                rv[j].y = __longlong_as_double((long long)k1.x);
-                rv[j].z = __longlong_as_double((long long)k1.y);
-            }
-            SFM_CSTAMP(3);
-            __syncthreads();
-            SFM_CSTAMP(2);
-            // list space for the pass: wave 0 scans the 64 per-wave counts, one atomic per workgroup
-            if (w == 0) {
+            SFM_CSTAMP(1);
+            for (uint32_t t0 = 0; t0 < mine || t0 == 0; t0 += kAccIter) {
+                __syncthreads();  // B2
+                SFM_CSTAMP(2);
+                // after the keyframe's last pass the workgroup arrives at once; under the arrival's round trip ...
+                const bool arrive = t0 + kAccIter >= mine && f + 1 < a.f1 && lane == 0;
+                unsigned prev = 0;
+                if (arrive) prev = chain_arrive_issue(a.bar);
+                // ... list space for the pass: a scan of the per-wave counts, one atomic per workgroup
                 const unsigned cnt = s_wave[lane];
                 unsigned inc = cnt;
                 for (int o = 1; o < kWave; o <<= 1) {
@@ -1827,47 +1772,170 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                     if ((int)lane >= o) inc += t;
                 }
                 s_off[lane] = inc - cnt;
-                if (lane == kWave - 1)
-                    s_base = inc ? atomicAdd(&a.list.cursor[(b % kListShards) * 8], (unsigned long long)inc) : 0ull;
-            }
-            // The barrier only orders the mask stores: after the keyframe's last pass the workgroup arrives as soon
-            // as its stores are acknowledged, and writes its records while the others arrive.
-            const bool last = t0 + kAccIter >= mine;
-            if (last && f + 1 < a.f1) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x == 0) chain_arrive(a.bar, G, f - a.f0 + 1);
+                unsigned long long res = 0ull;
+                if (lane == kWave - 1 && inc) res = atomicAdd(&a.list.cursor[(b % kListShards) * 8], (unsigned long long)inc);
+                if (arrive) chain_arrive_finish(a.bar, G, f - a.f0 + 1, prev);
                 SFM_CSTAMP(6);
-            } else {
-                __syncthreads();
+                if (lane == kWave - 1) s_base = res;
+                __syncthreads();  // B3
+                SFM_CSTAMP(4);
+                if (mine == 0) break;
             }
-            const unsigned long long base = s_base;
+        }
+    } else {
+        // ---- data waves
+        const unsigned dw = w - 1u;
+        for (uint32_t f = a.f0; f < a.f1 && !aborted; f++) {
+            const FrameDev &F = frames[f];
+            const VerdictDev &V = verdicts[f - aa.v_first];
+            uint8_t *const *later_mask = later_masks + V.later_begin;
+            const uint32_t npx = (uint32_t)F.W * (uint32_t)F.H;
+            const uint32_t runs = F.nbr_count ? (npx + kWave - 1) / kWave : 0u;              // 64-pixel runs of the keyframe
+            const uint32_t mine = (runs + G * kAccDataWaves - 1) / (G * kAccDataWaves);     // runs per data wave (same for every workgroup)
+            // Neither the verdicts nor the pixels they would mark depend on the masks: the first pass's verdicts and its
+            // stored hit pixels in the first four later neighbours are requested before the barrier opens (dense,
+            // coalesced loads for every pixel of the tile, accepted or not: four times the bytes, none of the latency;
+            // the loads are unconditional -- a lane without a pixel reads pixel 0, a missing neighbour slot the last
+            // one -- and nothing looks at their values before the barrier: no wait is placed in front of it)
+            uint32_t pixv[kAccIter], infov[kAccIter], h[kAccIter][4];
+            typedef unsigned long long ull2_t __attribute__((ext_vector_type(2)));
+            ull2_t r0[kAccIter], r1[kAccIter];
+            bool inv[kAccIter];
+            const uint32_t nl = V.n_later;
+            const uint32_t ql = nl ? nl - 1u : 0u;
 #pragma unroll
             for (int j = 0; j < kAccIter; j++) {
-                if (acc[j]) {
-                    const unsigned long long rel = base + s_off[j * kChainWaves + w] + pos[j];
-                    if (rel < a.list.shard_cap) {
-                        const unsigned long long idx = (unsigned long long)(b % kListShards) * a.list.shard_cap + rel;
-                        const VerdictRec r = rv[j];
-                        a.list.tag[idx] = (infov[j] & kVKeyRange) ? kEmpty : (((unsigned long long)F.order << 32) | pixv[j]);
-                        a.list.key[idx] = r.key;
-                        a.list.xyz[3 * idx + 0] = r.x;
-                        a.list.xyz[3 * idx + 1] = r.y;
-                        a.list.xyz[3 * idx + 2] = r.z;
-                    } else {
-                        err |= kErrListFull;
+                r0[j] = r1[j] = ull2_t{0ull, 0ull};
+                pixv[j] = (((uint32_t)j * kAccDataWaves + dw) * G + b) * kWave + lane;
+                inv[j] = (uint32_t)j < mine && pixv[j] < npx;
+                const uint32_t pa = inv[j] ? pixv[j] : 0u;
+                infov[j] = mine ? (uint32_t)ldg(V.info + pa) : 0u;  // (uniform conditions: an empty keyframe has nothing to read)
+#pragma unroll
+                for (int q = 0; q < 4; q++) h[j][q] = (mine && nl) ? ldg(V.hits + (size_t)min((uint32_t)q, ql) * npx + pa) : kNoHit;
+#if SFM_ACC_PREFETCH_REC
+                if (mine) {  // ... and the pixel's fused point (valid where the verdict is positive; read for every pixel: dense)
+                    const VerdictRec *rp = V.rec + pa;
+                    r0[j] = *(const __attribute__((address_space(1))) ull2_t *)rp;
+                    r1[j] = *((const __attribute__((address_space(1))) ull2_t *)rp + 1);
+                }
+#endif
+            }
+            __syncthreads();  // B1
+            if (s_go == 0u) {
+                err |= kErrBarrier;
+                break;
+            }
+            for (uint32_t t0 = 0; t0 < mine || t0 == 0; t0 += kAccIter) {
+                if (t0) {
+#pragma unroll
+                    for (int j = 0; j < kAccIter; j++) {
+                        pixv[j] = (((t0 + (uint32_t)j) * kAccDataWaves + dw) * G + b) * kWave + lane;
+                        inv[j] = t0 + (uint32_t)j < mine && pixv[j] < npx;
+                        const uint32_t pa = inv[j] ? pixv[j] : 0u;
+                        infov[j] = (uint32_t)ldg(V.info + pa);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) h[j][q] = nl ? ldg(V.hits + (size_t)min((uint32_t)q, ql) * npx + pa) : kNoHit;
+#if SFM_ACC_PREFETCH_REC
+                        const VerdictRec *rp = V.rec + pa;
+                        r0[j] = *(const __attribute__((address_space(1))) ull2_t *)rp;
+                        r1[j] = *((const __attribute__((address_space(1))) ull2_t *)rp + 1);
+#endif
                     }
                 }
+                // mask == 0 (:100): every lane with a pixel asks for its own byte, whatever its verdict -- all the loads
+                // of the pass are in flight together, one round trip (a load per branch was one round trip each)
+                uint32_t mv[kAccIter];
+#pragma unroll
+                for (int j = 0; j < kAccIter; j++) mv[j] = mask_load_coherent(F.mask + (inv[j] ? pixv[j] : 0u));
+#pragma unroll
+                for (int j = 0; j < kAccIter; j++) infov[j] = inv[j] ? infov[j] : 0u;
+                bool acc[kAccIter];
+                unsigned pos[kAccIter];
+#pragma unroll
+                for (int j = 0; j < kAccIter; j++) {
+                    const bool live = (infov[j] & kVCand) && mv[j] == 0u;
+                    acc[j] = live && (infov[j] & kVOk);
+                    c_gather += live ? (infov[j] & 0xFFFu) : 0u;
+                    c_hit += acc[j] ? ((infov[j] >> 12) & 0xFFFu) : 0u;
+                    if (acc[j] && (infov[j] & kVKeyRange)) err |= kErrKeyRange;
+                    const unsigned long long m = __ballot(acc[j]);
+                    pos[j] = lane_rank(m);
+                    if (lane == 0) s_wave[j * kAccDataWaves + dw] = (unsigned)__popcll(m);
+                }
+                // the marks (:152-154) of the accepted pixels, into the masks of keyframes still to come: the first four
+                // later neighbours from the registers ...
+#pragma unroll
+                for (int j = 0; j < kAccIter; j++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit) mask_store_coherent(later_mask[q] + h[j][q]);
+                // ... the others four at a time (unconditional loads: a lane without an accepted pixel reads element 0)
+                for (uint32_t s0 = 4; s0 < nl; s0 += 4) {
+                    uint32_t h2[kAccIter][4];
+#pragma unroll
+                    for (int j = 0; j < kAccIter; j++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            h2[j][q] = ldg(V.hits + (size_t)min(s0 + (uint32_t)q, nl - 1u) * npx + (acc[j] ? pixv[j] : 0u));
+#pragma unroll
+                    for (int j = 0; j < kAccIter; j++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (acc[j] && s0 + (uint32_t)q < nl && h2[j][q] != kNoHit)
+                                mask_store_coherent(later_mask[s0 + q] + h2[j][q]);
+                }
+#if SFM_ACC_PREFETCH_REC
+                // (measured slower: 38 KB of fused points per workgroup and keyframe read ahead for every pixel, 4.65 against
+                // 4.15 ms per C2 run)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+                // the accepted pixels' fused points (cold, scattered reads; unconditional loads: their number is fixed),
+                // requested now so that their round trip runs under the marks' acknowledgement and the arrival ...
+#pragma unroll
+                for (int j = 0; j < kAccIter; j++) {
+                    const VerdictRec *rp = V.rec + ((acc[j] && !SFM_DIAG_ACC_NOREC) ? pixv[j] : 0u);
+                    r0[j] = *(const __attribute__((address_space(1))) ull2_t *)rp;
+                    r1[j] = *((const __attribute__((address_space(1))) ull2_t *)rp + 1);
+                }
+                // ... but not in front of it: a wave's vector-memory operations complete in issue order, and the wait
+                // below leaves exactly the 2 * kAccIter loads just issued outstanding.  The barrier only orders the marks.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                static_assert(kAccIter == 4, "the counted wait names 2 * kAccIter loads");
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#endif
+                __syncthreads();  // B2
+                __syncthreads();  // B3
+                // the accepted pixels' list entries, behind the arrival
+                const unsigned long long base = s_base;
+#pragma unroll
+                for (int j = 0; j < kAccIter; j++) {
+                    if (acc[j]) {
+                        const unsigned long long rel = base + s_off[j * kAccDataWaves + dw] + pos[j];
+                        if (rel < a.list.shard_cap) {
+                            const unsigned long long idx = (unsigned long long)(b % kListShards) * a.list.shard_cap + rel;
+                            a.list.tag[idx] = (infov[j] & kVKeyRange) ? kEmpty : (((unsigned long long)F.order << 32) | pixv[j]);
+                            if (!SFM_DIAG_ACC_NOREC) {
+                                a.list.key[idx] = r0[j].x;
+                                a.list.xyz[3 * idx + 0] = __longlong_as_double((long long)r0[j].y);
+                                a.list.xyz[3 * idx + 1] = __longlong_as_double((long long)r1[j].x);
+                                a.list.xyz[3 * idx + 2] = __longlong_as_double((long long)r1[j].y);
+                            }
+                        } else {
+                            err |= kErrListFull;
+                        }
+                    }
+                }
+                // (s_wave is rewritten by the next pass's data waves, s_off and s_base by its scan: both behind syncs
+                // that every wave reaches only after it has read this pass's values)
+                if (mine == 0) break;
             }
-            if (STAMPS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            SFM_CSTAMP(4);
-            __syncthreads();  // s_wave and s_base are reused by the next pass / keyframe
-            if (mine == 0) break;
         }
     }
     // list boundaries of the group, as in fuse_chain_kernel (group == ~0: one launch per keyframe, no barrier words
-    // of its own; the host snapshots the cursors behind the group's last launch)
+    // of its own; the host snapshots the cursors behind the group's last launch).  The control wave has seen the value
+    // of every reservation of this workgroup: they are in the cursors.
+    __syncthreads();
     if (threadIdx.x == 0 && a.group != 0xFFFFFFFFu) {
         const unsigned left = __hip_atomic_fetch_add(a.bar + kBarDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (left == G - 1u) {
