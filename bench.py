@@ -173,9 +173,23 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
     for _ in range(args.warmup):
         step()
     barrier()
+    # per-rank breakdown of the timed steps (host clocks; N > 1): what the scaling model of DESIGN.md section 6 is made of
+    acc = {"phase_a_ms": 0.0, "wait_ms": 0.0, "phase_b_ms": 0.0, "chain_host_ms": 0.0, "mask_send_ms": 0.0, "exchange_ms": 0.0}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        if split is None:
+            step()
+            continue
+        split.run()
+        tx = time.perf_counter()
+        merger.exchange_and_reduce()
+        acc["exchange_ms"] += (time.perf_counter() - tx) * 1e3
+        sst = ctx.stats()
+        acc["phase_a_ms"] += sst["precompute_ms"]          # device time of this rank's verdicts (0 on rank 0: fused chain)
+        acc["phase_b_ms"] += sst["last_run_ms"]            # device time of this rank's chain (fused on rank 0, accept on the others)
+        acc["wait_ms"] += split.timing["wait"]             # blocked in recv for the predecessors' masks (phase A runs under it)
+        acc["chain_host_ms"] += split.timing["run"]
+        acc["mask_send_ms"] += split.timing["send"]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1 or force_exchange:
@@ -219,14 +233,17 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
     scan_avg_s = pst["scan_kernel_sum_ms"] * 1e-3 / launches
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload and not args.frames and tj.get("kernel") == kernel_name:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # (profiles/traffic_latest.json: the default run's dominant kernel; traffic_two_phase.json: accept_chain_kernel of
+    # `--two-phase`; both from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_summary.py)
+    for tname in ("traffic_latest.json", "traffic_two_phase.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if traffic is None and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload and not args.frames and tj.get("kernel") == kernel_name and world == 1:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
 
     # The roofs that bind this kernel, beside the contracted HBM figure (profiles/bounds_latest.json, made by
     # tools/profile_pass.sh + tools/profile_summary.py from rocprofv3 SQ counters and the micro-benchmarks):
@@ -268,7 +285,7 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak" if world == 1 else "strong",
+        "scaling": "single" if world == 1 else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic (exchange forced at one rank: functional check, not a measurement)" if force_exchange else "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a measurement)",
@@ -319,6 +336,11 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
                                     "phase B = the ordered accept/mark/emit chain (does not)"}
     if split is not None:
         out["mask_handover_bytes_rank0"] = split.bytes_sent // max(1, args.steps + args.warmup)
+        mine = {k: v / args.steps for k, v in acc.items()}
+        mine["keyframes"] = plan.end - plan.first
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        out["per_rank"] = rows
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, min(args.cpu_sample_frames, n_kf), W, H, voxel, t_dist)
     if rank == 0:

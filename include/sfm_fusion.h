@@ -191,11 +191,18 @@ int sfm_fusion_set_global_order(sfm_fusion_ctx *ctx, const uint32_t *order, uint
  * cloud at hand and fails, changing nothing, if that cloud has an index outside the new ranges). */
 int sfm_fusion_get_key_range(sfm_fusion_ctx *ctx, int64_t lo[3], int64_t hi[3]);
 int sfm_fusion_set_key_range(sfm_fusion_ctx *ctx, const int64_t lo[3], const int64_t hi[3]);
+/* After sfm_fusion_run: per axis the smallest and largest voxel index that the cloud at hand really holds (the
+ * indefinite index aside; lo > hi on an axis, or for a cloud, without any).  A packing's range is wider than the cloud
+ * (the default holds +-(2^20 - 1) whatever the cloud): ranks whose packings differ build the common one from the hull
+ * of these, not of their packings -- the hull of a default packing and a scanned one may need more than 63 bits where
+ * the clouds' own hull does not.  No reference counterpart. */
+int sfm_fusion_get_cloud_index_range(sfm_fusion_ctx *ctx, int64_t lo[3], int64_t hi[3]);
 /* After sfm_fusion_run: how many local winners each of n_parts owners gets (the owner is a hash of the three voxel
  * indices, independent of the packing). */
 int sfm_fusion_partition_counts(sfm_fusion_ctx *ctx, uint32_t n_parts, uint64_t *counts);
-/* sfm_fusion_partition_counts for callers that cannot allocate (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result; the kernel's per-owner
+/* sfm_fusion_partition_counts for callers that cannot allocate (tight serving loops, harnesses that forbid
+ * hipMalloc, a host thread beside a graph capture).  It still synchronises its stream and reads a pinned buffer on the
+ * host, so the call itself cannot be captured into a HIP graph.  No counterpart in the reference.  Same result; the kernel's per-owner
  * counters live in a static __device__ array of the library (8 KiB on every GPU the library runs on, held until the
  * process ends) instead of a buffer the library allocates, and the call performs no hipMalloc / hipFree.  Limit:
  * n_parts <= 1024 (SFM_E_CAPACITY beyond).  Calls on one GPU share that array: calls that overlap on one GPU (two

@@ -13,6 +13,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <iostream>
 #include <map>
 #include "cloud_writer.hpp"
 #include <ostream>
@@ -126,29 +127,57 @@ public:
         c.xyz.resize(3 * n); c.bgr.resize(3 * n); c.key.resize(3 * n); c.tag.resize(n);
         check(sfm_fusion_read_points(ctx, c.xyz.data(), c.bgr.data(), c.key.data(), c.tag.data()));
         check(sfm_fusion_get_stats(ctx, &stats_));
+        frame_before_.assign(order.size(), 0);
+        frame_after_.assign(order.size(), 0);
+        check(sfm_fusion_get_frame_counts(ctx, frame_before_.data(), frame_after_.data()));
         sfm_fusion_destroy(ctx);
         return c;
+    }
+
+    // The reference's progress log (dense_reconstruction.cpp:49, :54-58, :118-122): same lines, same order, written
+    // after the fusion (the GPU fuses all keyframes in one call).  On by default, to std::cout like the reference;
+    // set_progress_log(nullptr) silences it, any other stream redirects it.
+    void set_progress_log(std::ostream *log) { log_ = log; }
+    void write_progress_log(std::ostream &log) const
+    {
+        const std::size_t n = frame_before_.size();
+        for (std::size_t i = 0; i < n; i++) {
+            log << "Processing keyframe " << i << "/" << n << std::endl;           // :49
+            log << "Points before voxel filter: " << frame_before_[i] << std::endl;  // :118
+            log << "Points after voxel filter: " << frame_after_[i] << std::endl;    // :120
+            log << "\n";                                                           // :122
+        }
+        log << "processed all map frames" << std::endl;                              // :54
+        log << "Points before voxel removal: " << stats_.global_before << std::endl;  // :56
+        log << "Points after voxel removal: " << stats_.global_after << std::endl;    // :58
     }
 
     // dense_reconstruction.cpp:61-64: "x y z R G B" with default ostream formatting
     void reconstruct(std::ostream &os)
     {
         const Cloud c = fuse();
+        if (log_) write_progress_log(*log_);
         write_text_fast(os, c.xyz.data(), c.bgr.data(), c.size());  // same bytes as write_text (cloud_writer.hpp)
     }
     // binary PLY instead of text (no reference counterpart)
     void reconstruct_ply(std::ostream &os)
     {
         const Cloud c = fuse();
+        if (log_) write_progress_log(*log_);
         write_ply_binary(os, c.xyz.data(), c.bgr.data(), c.size());
     }
     const sfm_fusion_stats &stats() const { return stats_; }
+    // per selected keyframe: "Points before / after voxel filter" (:118-120)
+    const std::vector<std::uint64_t> &frame_before() const { return frame_before_; }
+    const std::vector<std::uint64_t> &frame_after() const { return frame_after_; }
 
 private:
     const Map &map_;
     int device_;
     sfm_fusion_params params_{};
     sfm_fusion_stats stats_{};
+    std::vector<std::uint64_t> frame_before_, frame_after_;
+    std::ostream *log_ = &std::cout;
 };
 
 }  // namespace sfm_amd

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -170,16 +171,21 @@ public:
         const std::uint32_t a0 = plan.first < plan.end ? plan.local.at(plan.first) : 0;
         check(sfm_fusion_set_active_range(ctx, a0, a0 + (std::uint32_t)(plan.end - plan.first)));
 
-        // 1. phase A while the predecessors chain (the first rank has nobody to wait for: fused chain)
-        if (rank_ > 0 && plan.end > plan.first) check(sfm_fusion_precompute(ctx));
-        // 2. masks in, this block's chain, masks out
+        // every mask buffer of the plan is made before anything runs: nothing is allocated between a predecessor's
+        // send and this rank's chain, or between the chain and the sends that the next rank waits for
         auto bytes_of = [&](const std::vector<std::size_t> &fr) {
             std::uint64_t b = 0;
             for (auto g : fr) b += px[g];
             return b;
         };
+        std::map<int, std::unique_ptr<DevBuf>> recv_buf, send_buf;
+        for (const auto &[q, fr] : plan.recvs) recv_buf[q] = std::make_unique<DevBuf>(bytes_of(fr));
+        for (const auto &[t, fr] : plan.sends) send_buf[t] = std::make_unique<DevBuf>(bytes_of(fr));
+        // 1. phase A while the predecessors chain (the first rank has nobody to wait for: fused chain)
+        if (rank_ > 0 && plan.end > plan.first) check(sfm_fusion_precompute(ctx));
+        // 2. masks in (ascending ranks: the order the senders finish in), this block's chain, masks out
         for (const auto &[q, fr] : plan.recvs) {
-            DevBuf buf(bytes_of(fr));
+            DevBuf &buf = *recv_buf[q];
             nccl(ncclRecv(buf.p, buf.n, ncclUint8, q, comm_, stream), "ncclRecv masks");
             hip(hipStreamSynchronize(stream), "sync");
             std::uint64_t off = 0;
@@ -190,40 +196,59 @@ public:
         }
         check(sfm_fusion_run(ctx));
         for (const auto &[t, fr] : plan.sends) {
-            DevBuf buf(bytes_of(fr));
             std::uint64_t off = 0;
             for_runs(plan, fr, [&](std::uint32_t first, std::uint32_t count, std::uint64_t nbytes) {
-                check(sfm_fusion_export_masks(ctx, first, count, (char *)buf.p + off, nbytes));
+                check(sfm_fusion_export_masks(ctx, first, count, (char *)send_buf[t]->p + off, nbytes));
                 off += nbytes;
             }, px);
-            nccl(ncclSend(buf.p, buf.n, ncclUint8, t, comm_, stream), "ncclSend masks");
+        }
+        if (!plan.sends.empty()) {  // all outgoing masks as one group: every peer on its own xGMI link at once
+            nccl(ncclGroupStart(), "ncclGroupStart");
+            for (const auto &[t, fr] : plan.sends)
+                nccl(ncclSend(send_buf[t]->p, send_buf[t]->n, ncclUint8, t, comm_, stream), "ncclSend masks");
+            nccl(ncclGroupEnd(), "ncclGroupEnd");
             hip(hipStreamSynchronize(stream), "sync");
         }
         // 3. voxel exchange
         std::vector<std::uint64_t> counts(world_);
         check(sfm_fusion_partition_counts(ctx, (std::uint32_t)world_, counts.data()));
-        const int row = world_ + 6;  // my record count for every owner, then my key range (lo[3], hi[3])
+        const int row = world_ + 6;  // my record count for every owner, then my key packing (lo[3], hi[3])
         std::vector<std::int64_t> mine(row), all((std::size_t)row * world_);
         for (int p = 0; p < world_; p++) mine[p] = (std::int64_t)counts[p];
         check(sfm_fusion_get_key_range(ctx, &mine[world_], &mine[world_ + 3]));
-        {
-            DevBuf s(row * 8), r((std::uint64_t)row * 8 * world_);
-            hip(hipMemcpyAsync(s.p, mine.data(), row * 8, hipMemcpyHostToDevice, stream), "H2D");
-            nccl(ncclAllGather(s.p, r.p, row, ncclInt64, comm_, stream), "ncclAllGather");
-            hip(hipMemcpyAsync(all.data(), r.p, (std::size_t)row * 8 * world_, hipMemcpyDeviceToHost, stream), "D2H");
+        auto all_gather = [&](const std::vector<std::int64_t> &in, std::vector<std::int64_t> &out) {
+            DevBuf s(in.size() * 8), r((std::uint64_t)in.size() * 8 * world_);
+            hip(hipMemcpyAsync(s.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, stream), "H2D");
+            nccl(ncclAllGather(s.p, r.p, in.size(), ncclInt64, comm_, stream), "ncclAllGather");
+            hip(hipMemcpyAsync(out.data(), r.p, in.size() * 8 * world_, hipMemcpyDeviceToHost, stream), "D2H");
             hip(hipStreamSynchronize(stream), "sync");
-        }
-        std::int64_t lo[3], hi[3];
-        for (int a = 0; a < 3; a++) {
-            lo[a] = mine[world_ + a];
-            hi[a] = mine[world_ + 3 + a];
-            for (int p = 0; p < world_; p++) {
-                lo[a] = std::min(lo[a], all[(std::size_t)p * row + world_ + a]);
-                hi[a] = std::max(hi[a], all[(std::size_t)p * row + world_ + 3 + a]);
+        };
+        all_gather(mine, all);
+        bool differ = false;
+        for (int p = 0; p < world_ && !differ; p++)
+            for (int k = 0; k < 6; k++) differ = differ || all[(std::size_t)p * row + world_ + k] != mine[world_ + k];
+        if (differ) {
+            // One packing on every rank: the hull of the index ranges the CLOUDS really have -- not of the packings (a
+            // rank still on the default packing holds +-(2^20 - 1) per axis whatever its cloud is, and the hull of that
+            // with a scanned range far from the origin can need more than 63 bits where the clouds' own hull does not).
+            std::vector<std::int64_t> real(6), reals((std::size_t)6 * world_);
+            check(sfm_fusion_get_cloud_index_range(ctx, &real[0], &real[3]));
+            all_gather(real, reals);
+            std::int64_t lo[3], hi[3];
+            for (int a = 0; a < 3; a++) {
+                bool any = false;
+                lo[a] = hi[a] = 0;
+                for (int p = 0; p < world_; p++) {
+                    const std::int64_t l = reals[(std::size_t)p * 6 + a], h = reals[(std::size_t)p * 6 + 3 + a];
+                    if (l > h) continue;  // no index on this axis in that rank's cloud
+                    lo[a] = any ? std::min(lo[a], l) : l;
+                    hi[a] = any ? std::max(hi[a], h) : h;
+                    any = true;
+                }
             }
+            check(sfm_fusion_set_key_range(ctx, lo, hi));  // re-encodes this rank's cloud
+            check(sfm_fusion_partition_counts(ctx, (std::uint32_t)world_, counts.data()));  // (arms export_records again)
         }
-        check(sfm_fusion_set_key_range(ctx, lo, hi));  // one packing on every rank (re-encodes this rank's cloud)
-        check(sfm_fusion_partition_counts(ctx, (std::uint32_t)world_, counts.data()));
         std::uint64_t n_local = 0, n_recv = 0;
         for (auto c : counts) n_local += c;
         for (int p = 0; p < world_; p++) n_recv += (std::uint64_t)all[(std::size_t)p * row + rank_];

@@ -35,6 +35,7 @@ int main()
     sfm_amd::DenseReconstruction dense{map};
     dense.params().T_dist = 5.0;
     dense.params().voxel_size = 1e-3;
+    dense.set_progress_log(&std::cerr);  // the reference logs to stdout and writes the cloud to ./dense.txt; here the cloud goes to stdout
     dense.reconstruct(std::cout);
     std::fprintf(stderr, "points %llu before %llu\n", (unsigned long long)dense.stats().n_vox,
                  (unsigned long long)dense.stats().n_acc);

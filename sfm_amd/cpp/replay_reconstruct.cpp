@@ -1,6 +1,6 @@
 // replay_reconstruct.cpp -- the fusion half of the reference's `reconstruct` executable
 // (src/reconstruct.cpp:69-73) over a keyframe replay dump:
-//     replay_reconstruct <dump.sfmr> <out> [--ply] [--voxel-size V] [--t-dist T] [--rewrite <copy.sfmr>] [--timing]
+//     replay_reconstruct <dump.sfmr> <out> [--ply] [--voxel-size V] [--t-dist T] [--rewrite <copy.sfmr>] [--timing] [--quiet]
 // Host-only C++ over the C ABI (libsfm_fusion.so); --rewrite re-exports the dump through the C++
 // writer (used by the tests to check the two implementations of the format against each other).
 #include "replay.hpp"
@@ -24,7 +24,7 @@ int main(int argc, char **argv)
         const auto t0 = clk::now();
         sfm_amd::Replay replay(argv[1]);
         const auto t1 = clk::now();
-        bool ply = false, timing = false;
+        bool ply = false, timing = false, quiet = false;
         std::string rewrite;
         sfm_amd::DenseReconstruction dense{replay.map};
         for (int i = 3; i < argc; i++) {
@@ -34,6 +34,7 @@ int main(int argc, char **argv)
             else if (a == "--t-dist" && i + 1 < argc) dense.params().T_dist = std::atof(argv[++i]);
             else if (a == "--rewrite" && i + 1 < argc) rewrite = argv[++i];
             else if (a == "--timing") timing = true;
+            else if (a == "--quiet") quiet = true;  // no progress log (the reference always prints it, dense_reconstruction.cpp:49-58)
             else { std::cerr << "unknown option " << a << "\n"; return 2; }
         }
         if (!rewrite.empty()) sfm_amd::write_replay(rewrite, replay.map);
@@ -42,6 +43,7 @@ int main(int argc, char **argv)
         const auto t2 = clk::now();
         const sfm_amd::Cloud cloud = dense.fuse();
         const auto t3 = clk::now();
+        if (!quiet) dense.write_progress_log(std::cout);
         if (ply) sfm_amd::write_ply_binary(out, cloud.xyz.data(), cloud.bgr.data(), cloud.size());
         else sfm_amd::write_text_fast(out, cloud.xyz.data(), cloud.bgr.data(), cloud.size());
         out.flush();

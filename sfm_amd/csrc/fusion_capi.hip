@@ -72,6 +72,9 @@ struct HostCounters {  // pinned snapshot read back after the frame loop
     // range-scan run: index range of every fused point, per shard.  Last, and outside the per-run memset: a two-phase
     // run fills it in sfm_fusion_precompute, before sfm_fusion_run's own launches
     alignas(64) KeyRangeDev key_scan[kStatShards];
+    // error words of sfm_fusion_precompute's verdict_kernel launches (phase A runs before sfm_fusion_run's memset and
+    // performs every division of the two-phase path): zeroed by sfm_fusion_precompute, read with every run's results
+    alignas(64) StatShard pa_stat[kStatShards];
 };
 
 }  // namespace
@@ -193,6 +196,7 @@ struct sfm_fusion_ctx {
     DevBuf<VerdictDev> d_verdicts;
     DevBuf<uint8_t *> d_later_masks;   // masks of every active keyframe's later neighbours (VerdictDev::later_begin)
     bool have_verdicts = false;
+    bool verdict_plain = false;        // phase A met a division operand outside the shared range: verdict_kernel divides plainly
     bool big_k = false;                // a keyframe has more filtered neighbours than the fused kernels hold (kMaxK)
     bool auto_precompute = false;      // SFM_PRECOMPUTE=1: every run goes through the two phases (tests)
     bool verdicts_ran = false;
@@ -202,6 +206,8 @@ struct sfm_fusion_ctx {
     bool have_result = false;
     sfm_fusion_stats stats;
     std::vector<uint64_t> fbefore, fafter;
+    uint64_t *h_fcounts = nullptr;     // pinned: per-keyframe before | after counts of the last run (2 * h_fcounts_n words)
+    size_t h_fcounts_n = 0;
     std::string err;
 };
 
@@ -258,6 +264,10 @@ unsigned long long *dev_cursor(sfm_fusion_ctx *c)
 StatShard *dev_stat(sfm_fusion_ctx *c)
 {
     return reinterpret_cast<StatShard *>(c->d_small + offsetof(HostCounters, stat));
+}
+StatShard *dev_pa_stat(sfm_fusion_ctx *c)
+{
+    return reinterpret_cast<StatShard *>(c->d_small + offsetof(HostCounters, pa_stat));
 }
 
 int fail(sfm_fusion_ctx *c, int code, const std::string &msg)
@@ -439,7 +449,15 @@ int build_layout(sfm_fusion_ctx *c)
     std::vector<FrameDev> &fd = c->h_frames;
     fd.assign(n, FrameDev());
     c->have_verdicts = false;
+    c->verdict_plain = false;
     c->big_k = false;
+    if (c->h_fcounts_n < n) {
+        if (c->h_fcounts) HIP_TRY(c, hipHostFree(c->h_fcounts));
+        c->h_fcounts = nullptr;
+        c->h_fcounts_n = 0;
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_fcounts, std::max<size_t>(n, 1) * 2 * sizeof(uint64_t), hipHostMallocDefault));
+        c->h_fcounts_n = n;
+    }
     std::vector<uint32_t> &nbr = c->h_nbr;
     nbr.clear();
     // lookup tables, one per distinct (f, c, extent) / focal length
@@ -831,9 +849,14 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     HIP_TRY(c, hipStreamWaitEvent(sa, c->ev_b_done, 0));
     HIP_TRY(c, hipEventRecord(c->ev[3], sa));
     HIP_TRY(c, hipMemcpyAsync(c->h_small, c->d_small, kSmallBytes, hipMemcpyDeviceToHost, sa));
-    HIP_TRY(c, hipStreamSynchronize(sa));
+    if (n)  // the per-keyframe counts ride behind the counters: z_fbefore | z_fafter are one block of 2n words
+        HIP_TRY(c, hipMemcpyAsync(c->h_fcounts, c->z_fbefore, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost, sa));
+    HIP_TRY(c, hipStreamSynchronize(sa));  // the run's one host synchronisation
     uint32_t err = c->h_small->ctr.err;
     for (int s = 0; s < kStatShards; s++) err |= c->h_small->stat[s].err;
+    if (use_verdicts)  // phase A's divisions happened in sfm_fusion_precompute
+        for (int s = 0; s < kStatShards; s++)
+            if (c->h_small->pa_stat[s].err & kErrDivRange) err |= kErrDivRangeA;
     uint64_t n_list = 0;
     for (int s = 0; s < kListShards; s++) {
         if (c->h_small->cursor[s * 8] > shard_cap) err |= kErrListFull;
@@ -1002,6 +1025,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->h_part) (void)hipHostFree(c->h_part);
+    if (c->h_fcounts) (void)hipHostFree(c->h_fcounts);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_pa)
@@ -1254,6 +1278,16 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
         if ((rc = run_once(c, table_cap, shard_cap, out_cap, &err))) return rc;
         const bool crowded = !err && !fixed_tab && c->h_small->ctr.table_used * 2 > table_cap;
         if (!err && !crowded) break;
+        if (err & kErrDivRangeA) {
+            // phase A (verdict_kernel) met a division operand outside the shared-reciprocal range: its verdicts are void.
+            // Recompute them with plain divisions and run again; counted like a fallback of the fused chain.
+            if (c->verdict_plain) return fail(c, SFM_E_HIP, "division-range error from a kernel that divides plainly");
+            c->verdict_plain = true;
+            c->have_verdicts = false;
+            c->chain_fallbacks++;
+            if ((rc = sfm_fusion_precompute(c))) return rc;
+            continue;
+        }
         if (err & (kErrBarrier | kErrDivRange)) {
             // kErrBarrier: the persistent kernel's workgroups were not all resident within the time limit
             // (another process or stream holds CUs).  Nothing hangs: every workgroup has left.
@@ -1335,12 +1369,8 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
     st.table_capacity = table_cap;
     st.table_used = c->h_small->ctr.table_used;
     st.max_probe = c->h_small->ctr.max_probe;
-    c->fbefore.assign(n, 0);
-    c->fafter.assign(n, 0);
-    if (n) {
-        HIP_TRY(c, hipMemcpy(c->fbefore.data(), c->z_fbefore, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->fafter.data(), c->z_fafter, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    }
+    c->fbefore.assign(c->h_fcounts, c->h_fcounts + n);  // copied behind the counters, before the run's one synchronisation
+    c->fafter.assign(c->h_fcounts + n, c->h_fcounts + 2 * n);
     st.n_acc = std::accumulate(c->fbefore.begin(), c->fbefore.end(), (uint64_t)0);
     st.global_before = std::accumulate(c->fafter.begin(), c->fafter.end(), (uint64_t)0);
     float ms = 0;
@@ -1399,7 +1429,7 @@ int sfm_fusion_precompute(sfm_fusion_ctx *c)
     const size_t a0 = std::min<size_t>(c->act_first, n), a1 = std::max(a0, std::min<size_t>(c->act_end, n));
     const DevParams P = make_dev_params(c);
     // the shared-reciprocal divisions need operands in their range, for the keyframe and for its neighbours
-    bool shared = true;
+    bool shared = !c->verdict_plain;
     for (size_t i = 0; shared && i < n && !div_trust(); i++)
         shared = chain_div_ok(P, c->frames[i].K, c->frames[i].W, c->frames[i].H, c->h_frames[i].Twk, c->h_frames[i].Tkw);
     // arena: per active keyframe info u32[P] | rec 32 B [P] | hits u32 [n_later][P], each 256-byte aligned
@@ -1424,6 +1454,8 @@ int sfm_fusion_precompute(sfm_fusion_ctx *c)
         off[i - a0] = total;
         total += up(px * 4) + up(px * sizeof(VerdictRec)) + up(px * 4 * V.n_later);
     }
+    // an earlier phase A or chain may still be reading the tables refilled below (the stream does not block the host)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     if ((rc = ensure(c, c->d_verdict_arena, total))) return rc;
     if ((rc = ensure(c, c->d_verdicts, hv.size()))) return rc;
     if ((rc = ensure(c, c->d_later_masks, later.size()))) return rc;
@@ -1441,6 +1473,7 @@ int sfm_fusion_precompute(sfm_fusion_ctx *c)
     if (!hv.empty())
         HIP_TRY(c, hipMemcpy(c->d_verdicts.p, hv.data(), hv.size() * sizeof(VerdictDev), hipMemcpyHostToDevice));
     if (c->key_scan && (rc = reset_key_scan(c))) return rc;  // the scan of a two-phase run happens here
+    HIP_TRY(c, hipMemsetAsync(dev_pa_stat(c), 0, sizeof(StatShard) * kStatShards, c->stream));
     // phase A: no order between keyframes; one launch per 32 keyframes keeps the grids moderate
     HIP_TRY(c, hipEventRecord(c->ev_pa[0], c->stream));
     for (size_t g0 = a0; g0 < a1; g0 += kGroup) {
@@ -1452,11 +1485,11 @@ int sfm_fusion_precompute(sfm_fusion_ctx *c)
         if (shared)
             hipLaunchKernelGGL(verdict_kernel<true>, grid, dim3(256), 0, c->stream, (const FrameDev *)c->d_frames.p,
                                (const FrameDev *)c->d_nbrpack.p, (const VerdictDev *)c->d_verdicts.p, (uint32_t)g0,
-                               (uint32_t)(g0 - a0), P, dev_stat(c));
+                               (uint32_t)(g0 - a0), P, dev_pa_stat(c));
         else
             hipLaunchKernelGGL(verdict_kernel<false>, grid, dim3(256), 0, c->stream, (const FrameDev *)c->d_frames.p,
                                (const FrameDev *)c->d_nbrpack.p, (const VerdictDev *)c->d_verdicts.p, (uint32_t)g0,
-                               (uint32_t)(g0 - a0), P, dev_stat(c));
+                               (uint32_t)(g0 - a0), P, dev_pa_stat(c));
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_pa[1], c->stream));
@@ -1603,6 +1636,29 @@ int sfm_fusion_set_key_range(sfm_fusion_ctx *c, const int64_t lo[3], const int64
     c->key = nk;
     for (int a = 0; a < 3; a++) c->key_bits[a] = bits_for_range(nk.lo[a], nk.hi[a]);
     c->have_verdicts = false;  // their records hold packed keys
+    return SFM_OK;
+}
+
+int sfm_fusion_get_cloud_index_range(sfm_fusion_ctx *c, int64_t lo[3], int64_t hi[3])
+{
+    if (!c || !lo || !hi) return SFM_E_INVALID;
+    if (!c->have_result) return fail(c, SFM_E_INVALID, "no result: call sfm_fusion_run first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = reset_key_scan(c))) return rc;  // (the scan words are free between runs) shard 0 = an empty range
+    hipStream_t s = c->stream;
+    if (c->n_out) {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((c->n_out + 255) / 256, 1024);
+        hipLaunchKernelGGL(key_range_kernel, dim3(blocks), dim3(256), 0, s, (const unsigned long long *)c->d_out_key.p,
+                           (unsigned long long)c->n_out, key_bits_of(c), dev_key_scan(c));
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipMemcpyAsync(&c->h_small->key_scan[0], dev_key_scan(c), sizeof(KeyRangeDev), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (int a = 0; a < 3; a++) {
+        lo[a] = c->h_small->key_scan[0].lo[a];
+        hi[a] = c->h_small->key_scan[0].hi[a];
+    }
     return SFM_OK;
 }
 
@@ -1799,9 +1855,9 @@ const char *sfm_fusion_last_error(sfm_fusion_ctx *c) { return c ? c->err.c_str()
 const char *sfm_fusion_version(void)
 {
 #if SFM_DIV_CHECKED
-    return "sfm_fusion 0.2 (gfx950) div-checked";
+    return "sfm_fusion 0.3 (gfx950) div-checked";
 #else
-    return "sfm_fusion 0.2 (gfx950)";
+    return "sfm_fusion 0.3 (gfx950)";
 #endif
 }
 

@@ -72,6 +72,7 @@ constexpr uint32_t kErrListFull = 4u;
 constexpr uint32_t kErrBarrier = 8u;  // fuse_chain_kernel: a device-wide barrier timed out
 constexpr uint32_t kErrOutFull = 16u;  // finalize_kernel: more winners than output slots
 constexpr uint32_t kErrDivRange = 32u; // fuse_chain_kernel: a division operand outside div_pair's range
+constexpr uint32_t kErrDivRangeA = 64u; // host only: the same from verdict_kernel (phase A of the two-phase chain)
 
 struct FrameDev {
     double K[4];      // fx fy cx cy
@@ -2286,6 +2287,36 @@ __global__ __launch_bounds__(256) void rekey_kernel(const unsigned long long *ou
             ok = axis_code_range(v[a] == 0x8000000000000000ull ? INT64_MIN : (long long)v[a], to.lo[a], to.hi[a], code[a]) && ok;
         if (!ok) atomicOr(&ctr->err, kErrKeyRange);
         dst[i] = (code[0] << (to.b[1] + to.b[2])) | (code[1] << to.b[2]) | code[2];
+    }
+}
+
+// The smallest and largest voxel index per axis over a cloud's packed keys (the indefinite index aside): what a rank
+// tells the others before they agree on a common packing.  out starts as an empty range (lo = max, hi = min).
+__global__ __launch_bounds__(256) void key_range_kernel(const unsigned long long *out_key, unsigned long long n, KeyPack kp,
+                                                        KeyRangeDev *out)
+{
+    long long lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long v[3];
+        unpack_key_dev(out_key[i], kp, v);
+        for (int a = 0; a < 3; a++) {
+            if (v[a] == 0x8000000000000000ull) continue;
+            const long long k = (long long)v[a];
+            lo[a] = k < lo[a] ? k : lo[a];
+            hi[a] = k > hi[a] ? k : hi[a];
+        }
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long l2 = __shfl_xor(lo[a], o), h2 = __shfl_xor(hi[a], o);
+            lo[a] = l2 < lo[a] ? l2 : lo[a];
+            hi[a] = h2 > hi[a] ? h2 : hi[a];
+        }
+        if (lane_id() == 0 && lo[a] <= hi[a]) {
+            __hip_atomic_fetch_min(&out->lo[a], lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(&out->hi[a], hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

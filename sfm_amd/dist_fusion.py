@@ -169,7 +169,10 @@ class SequenceSplit:
     """One pass of the keyframe chain of ONE sequence over all ranks: receive the masks the earlier blocks left,
     fuse this rank's block, send the masks of later keyframes on.  `ctx` provides clear_imported_masks(),
     import_masks(first, count, ptr, nbytes), run(), export_masks(first, count, ptr, nbytes) -- sfm_amd.fusion.
-    FusionContext on a GPU, an oracle-backed stand-in in the CPU tests.  `px` maps a global keyframe to W*H."""
+    FusionContext on a GPU, an oracle-backed stand-in in the CPU tests.  `px` maps a global keyframe to W*H.
+    The mask buffers (device, and host staging where the backend is gloo) are made once per plan, here.
+    After run(): `timing` = host-side milliseconds of the pass (phase_a_issue, wait = blocked in recv for the
+    predecessors' masks, import, run, send)."""
 
     def __init__(self, ctx, plan: RankPlan, px, rank: int, world: int, device, group=None, precompute=None):
         self.ctx, self.plan, self.px = ctx, plan, px
@@ -179,46 +182,70 @@ class SequenceSplit:
         self.rank, self.world, self.device, self.group = rank, world, device, group
         self.bytes_sent = 0
         self.bytes_received = 0
+        self.timing = {}
+        self._recv_buf, self._send_buf, self._host_buf = {}, {}, {}
+        for peer, frames, bufs in [(q, f, self._recv_buf) for q, f in plan.recvs.items()] + \
+                                  [(r, f, self._send_buf) for r, f in plan.sends.items()]:
+            n = sum(px(g) for g in frames)
+            bufs[peer] = torch.empty(max(n, 1), dtype=torch.uint8, device=device)
+            if self._staged(bufs[peer]):
+                self._host_buf[(id(bufs), peer)] = torch.empty(max(n, 1), dtype=torch.uint8).pin_memory() \
+                    if torch.cuda.is_available() else torch.empty(max(n, 1), dtype=torch.uint8)
 
     def _staged(self, t):
         return t.is_cuda and dist.get_backend(self.group) == "gloo"  # gloo moves host memory only
 
     def run(self):
+        import time
         ctx, plan = self.ctx, self.plan
+        t = {"phase_a_issue": 0.0, "wait": 0.0, "import": 0.0, "run": 0.0, "send": 0.0}
+        t0 = time.perf_counter()
         ctx.clear_imported_masks()
         if self.precompute:
             ctx.precompute()  # asynchronous: overlaps the wait for the predecessors' masks
+        t["phase_a_issue"] = time.perf_counter() - t0
         for q, frames in plan.recvs.items():  # ascending ranks: the order the senders finish in
             n = sum(self.px(g) for g in frames)
-            buf = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
+            buf = self._recv_buf[q]
+            t0 = time.perf_counter()
             if self._staged(buf):
-                h = torch.empty(max(n, 1), dtype=torch.uint8)
+                h = self._host_buf[(id(self._recv_buf), q)]
                 dist.recv(h, src=q, group=self.group)
                 buf.copy_(h)
             else:
                 dist.recv(buf, src=q, group=self.group)
             if buf.is_cuda:
                 torch.cuda.current_stream(buf.device).synchronize()
+            t1 = time.perf_counter()
+            t["wait"] += t1 - t0
             off = 0
             for first, count in _runs([plan.local[g] for g in frames]):
                 nb = sum(self.px(plan.frames[i]) for i in range(first, first + count))
                 ctx.import_masks(first, count, buf.data_ptr() + off, nb)
                 off += nb
+            t["import"] += time.perf_counter() - t1
             self.bytes_received += n
+        t0 = time.perf_counter()
         ctx.run()
+        t1 = time.perf_counter()
+        t["run"] = t1 - t0
         for r, frames in plan.sends.items():
             n = sum(self.px(g) for g in frames)
-            buf = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
+            buf = self._send_buf[r]
             off = 0
             for first, count in _runs([plan.local[g] for g in frames]):
                 nb = sum(self.px(plan.frames[i]) for i in range(first, first + count))
                 ctx.export_masks(first, count, buf.data_ptr() + off, nb)
                 off += nb
             if self._staged(buf):
-                dist.send(buf.cpu(), dst=r, group=self.group)
+                h = self._host_buf[(id(self._send_buf), r)]
+                h.copy_(buf)
+                dist.send(h, dst=r, group=self.group)
             else:
                 dist.send(buf, dst=r, group=self.group)
             self.bytes_sent += n
+        t["send"] = time.perf_counter() - t1
+        self.timing = {k: v * 1e3 for k, v in t.items()}
 
 
 class VoxelExchange:
@@ -266,11 +293,31 @@ class VoxelExchange:
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         got = recv_counts.tolist()
         rc = [int(row[0]) for row in got]
-        c_lo = tuple(min([lo[a]] + [int(row[1 + a]) for row in got]) for a in range(3))
-        c_hi = tuple(max([hi[a]] + [int(row[4 + a]) for row in got]) for a in range(3))
-        if (c_lo, c_hi) != (tuple(lo), tuple(hi)):
-            self.ctx.set_key_range(c_lo, c_hi)                 # re-encodes this rank's cloud
-            assert self.ctx.partition_counts(self.world) == counts
+        packings = {(tuple(lo), tuple(hi))} | {(tuple(int(x) for x in row[1:4]), tuple(int(x) for x in row[4:7])) for row in got}
+        if len(packings) > 1:
+            # The ranks pack differently (every rank sees the same rows, so every rank takes this branch).  The common
+            # packing is the hull of the index ranges the CLOUDS really have, not of the packings: a rank still on the
+            # default packing holds +-(2^20 - 1) on every axis whatever its cloud is, and the hull of that with a
+            # scanned range far from the origin can need more than 63 bits where the clouds' own hull does not.
+            if hasattr(self.ctx, "cloud_index_range"):
+                r_lo, r_hi = self.ctx.cloud_index_range()
+            else:
+                r_lo, r_hi = lo, hi
+            mine = torch.tensor([*r_lo, *r_hi], dtype=torch.int64, device=self.device)
+            if staged:
+                mine = mine.cpu()
+            everyone = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(everyone, mine, group=self.group)
+            rows = [[int(x) for x in e.tolist()] for e in everyone]
+            c_lo, c_hi = [], []
+            for a in range(3):
+                have = [(row[a], row[3 + a]) for row in rows if row[a] <= row[3 + a]]   # lo > hi: no index on this axis
+                c_lo.append(min(x for x, _ in have) if have else 0)
+                c_hi.append(max(y for _, y in have) if have else 0)
+            self.ctx.set_key_range(tuple(c_lo), tuple(c_hi))       # re-encodes this rank's cloud
+            again = self.ctx.partition_counts(self.world)          # (arms export_records for the re-encoded cloud)
+            if again != counts:
+                raise RuntimeError("voxel owners changed with the key packing: %r != %r" % (again, counts))
         mark("all_to_all counts")
         send = torch.empty(max(n_local, 1) * RECORD_BYTES, dtype=torch.uint8, device=self.device)
         self.ctx.export_records(send.data_ptr(), n_local * RECORD_BYTES)

@@ -17,6 +17,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import sys
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -40,6 +41,7 @@ EXPORTS = [
     "sfm_fusion_partition_counts_noalloc", "sfm_fusion_set_active_range", "sfm_fusion_import_masks",
     "sfm_fusion_clear_imported_masks", "sfm_fusion_export_masks", "sfm_fusion_precompute",
     "sfm_fusion_add_keyframe_se3", "sfm_fusion_se3_exp", "sfm_fusion_get_key_range", "sfm_fusion_set_key_range",
+    "sfm_fusion_get_cloud_index_range",
 ]
 SFM_RECORD_BYTES = 48
 
@@ -111,6 +113,7 @@ def load_library():
     L.sfm_fusion_set_global_order.argtypes = [vp, C.POINTER(u32), u32]
     L.sfm_fusion_get_key_range.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sfm_fusion_set_key_range.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.sfm_fusion_get_cloud_index_range.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sfm_fusion_partition_counts.argtypes = [vp, u32, C.POINTER(u64)]
     L.sfm_fusion_partition_counts_noalloc.argtypes = [vp, u32, C.POINTER(u64)]
     L.sfm_fusion_export_records.argtypes = [vp, vp, u64]
@@ -267,6 +270,14 @@ class FusionContext:
         a = (C.c_int64 * 3)(*[int(x) for x in lo])
         b = (C.c_int64 * 3)(*[int(x) for x in hi])
         self._check(self._L.sfm_fusion_set_key_range(self._h, a, b))
+
+    def cloud_index_range(self):
+        """(lo, hi): per axis the smallest and largest voxel index of the cloud at hand (the indefinite index aside);
+        lo > hi on an axis without any.  What ranks exchange before they agree on a common key packing."""
+        lo = (C.c_int64 * 3)()
+        hi = (C.c_int64 * 3)()
+        self._check(self._L.sfm_fusion_get_cloud_index_range(self._h, lo, hi))
+        return tuple(int(x) for x in lo), tuple(int(x) for x in hi)
 
     def partition_counts(self, n_parts: int):
         counts = (C.c_uint64 * n_parts)()
@@ -443,8 +454,25 @@ class DenseReconstruction:
         self.ctx.run()
         return self.ctx.read_points()
 
-    def reconstruct(self, os):
+    def progress_log(self):
+        """The reference's progress log (dense_reconstruction.cpp:49, :54-58, :118-122) as a string: same lines, same
+        order, from the counts of the last fuse()."""
+        before, after = self.ctx.frame_counts()
+        st = self.ctx.stats()
+        n = len(before)
+        out = []
+        for i in range(n):
+            out += [f"Processing keyframe {i}/{n}", f"Points before voxel filter: {int(before[i])}",
+                    f"Points after voxel filter: {int(after[i])}", ""]
+        out += ["processed all map frames", f"Points before voxel removal: {st['global_before']}",
+                f"Points after voxel removal: {st['global_after']}"]
+        return "\n".join(out) + "\n"
+
+    def reconstruct(self, os, log=sys.stdout):
+        """Writes the cloud to `os` and, like the reference, its progress log to stdout (log=None: silent)."""
         xyz, bgr, _, _ = self.fuse()
+        if log is not None:
+            log.write(self.progress_log())
         write_cloud(os, xyz, bgr)
 
 

@@ -30,7 +30,7 @@ def test_single_gpu_line(fusion_path):
     j = _last_json(r.stdout)
     for k in NEEDED + ("cpu_baseline",):
         assert k in j, k
-    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "single" and j["vs_baseline"] is None
     assert j["value"] > 0 and j["dtype"] == "f64" and j["config"]["workload"] == "tiny_24kf_160x120"
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["kernel"] == "fuse_chain_kernel" and rf["peak"] == 8000.0
@@ -56,6 +56,14 @@ def test_two_rank_rehearsal_line(fusion_path):
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "REHEARSAL" in j["data"]
     assert j["output_points"] > 0 and j["value"] > 0 and j["mask_handover_bytes_rank0"] > 0
     assert j["config"]["keyframes"] == 24 and j["config"]["keyframes_per_gpu"] == 12
+    # the per-rank breakdown the scaling model of DESIGN.md section 6 is checked against
+    pr = j["per_rank"]
+    assert len(pr) == 2 and sum(r["keyframes"] for r in pr) == 24
+    for r in pr:
+        for k in ("phase_a_ms", "wait_ms", "phase_b_ms", "exchange_ms", "mask_send_ms"):
+            assert r[k] >= 0.0, (k, r)
+    assert pr[0]["phase_a_ms"] == 0.0 and pr[1]["phase_a_ms"] > 0.0      # rank 0 runs the fused chain, rank 1 the two phases
+    assert pr[0]["phase_b_ms"] > 0.0 and pr[1]["phase_b_ms"] > 0.0 and pr[1]["wait_ms"] > 0.0
     # the same sequence on one rank: the split must not change the cloud
     r1 = subprocess.run([sys.executable, "bench.py", "--workload", "tiny_24kf_160x120", "--steps", "1", "--warmup", "0",
                          "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=280)

@@ -31,3 +31,11 @@ def test_facade_example_matches_oracle():
     fusion.write_cloud(buf, want.xyz, want.bgr)
     assert r.stdout == buf.getvalue()
     assert f"points {want.key.shape[0]} before {want.counters['n_acc']}" in r.stderr
+    # the reference's progress log (dense_reconstruction.cpp:49, :54-58, :118-122), line for line, counts from the oracle
+    log = []
+    for i in range(3):
+        log += [f"Processing keyframe {i}/3", f"Points before voxel filter: {int(want.frame_before[i])}",
+                f"Points after voxel filter: {int(want.frame_after[i])}", ""]
+    log += ["processed all map frames", f"Points before voxel removal: {want.global_before}",
+            f"Points after voxel removal: {want.global_after}"]
+    assert r.stderr.split("\n")[:len(log)] == log, r.stderr

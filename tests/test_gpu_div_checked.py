@@ -43,6 +43,18 @@ if mode == "sweep":
         ran += st["fused_chain"]
     assert ran >= 35, ran          # the chain kernels really ran (scenes without keyframes aside)
     print("SWEEP-OK", ran)
+elif mode == "trust_verdict":
+    # the same on the two-phase chain (SFM_PRECOMPUTE=1): every division of that path is in phase A, whose error word
+    # must survive the run's memset; the verdicts are recomputed with plain divisions and the run repeated
+    frames = scenes.plane_pair()
+    for f in frames:
+        f["T_kw"] = f["T_kw"] * 2.0 ** -500
+    op, gp = both_params()
+    g = run_gpu(frames, gp)
+    assert_same_cloud(g, oracle.fuse(frames, op))
+    st = g["stats"]
+    assert st["chain_fallbacks"] == 1 and st["precomputed"] == 1, st
+    print("TRUST-VERDICT-OK")
 else:
     frames = scenes.plane_pair()
     for f in frames:
@@ -78,6 +90,9 @@ def test_no_operand_leaves_the_shared_range_where_the_host_bound_says_yes(fusion
 
 
 def test_the_checked_build_catches_what_the_host_bound_refuses(fusion_path):
-    if fusion_path != "chain":
-        pytest.skip("once, on the fused chain")
-    assert "TRUST-OK" in _run("trust", SFM_CHAIN_DIV_TRUST="1")
+    if fusion_path == "pair":
+        pytest.skip("the kernel pair divides plainly")
+    if fusion_path == "verdict":   # phase A's error word used to be erased by the run's memset
+        assert "TRUST-VERDICT-OK" in _run("trust_verdict", SFM_CHAIN_DIV_TRUST="1", SFM_PRECOMPUTE="1")
+    else:
+        assert "TRUST-OK" in _run("trust", SFM_CHAIN_DIV_TRUST="1")

@@ -148,12 +148,12 @@ def test_blockwise_oracle_equals_the_whole_oracle():
             assert np.array_equal(xyz[first_of_key], want.xyz)
 
 
-def _worker(rank, world, port, out_dir, closure):
+def _worker(rank, world, port, out_dir, closure, n_kf=10):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    frames = _sequence(10, closure=closure)
-    plans = dist_fusion.plan_sequence([f["nbrs"] for f in frames], [48 * 36] * 10, world)
+    frames = _sequence(n_kf, closure=closure)
+    plans = dist_fusion.plan_sequence([f["nbrs"] for f in frames], [48 * 36] * n_kf, world)
     plan = plans[rank]
     ctx = OracleBlockCtx(_local_frames(frames, plan), plan.active_local, plan.frames)
     split = dist_fusion.SequenceSplit(ctx, plan, lambda g: 48 * 36, rank, world, torch.device("cpu"))
@@ -210,6 +210,34 @@ def test_two_ranks_one_sequence_equals_single_process(tmp_path):
 
 def test_three_ranks_with_a_long_range_edge(tmp_path):
     _check(tmp_path, 3, closure=True)
+
+
+def test_more_ranks_than_the_split_has_blocks_for(tmp_path):
+    """SequenceSplit followed by VoxelExchange end to end with a rank whose block is EMPTY (3 keyframes
+    over 4 ranks) and an edge that jumps a block (keyframe 0 names keyframe 2: the rank between them is skipped by that
+    mask transfer).  The empty rank still takes part in every collective and owns its share of the voxels."""
+    world, n_kf = 4, 3
+    frames = _sequence(n_kf, closure=True)                 # closure: keyframe 1 names the last keyframe as well
+    nbrs = [f["nbrs"] for f in frames]
+    plans = dist_fusion.plan_sequence(nbrs, [48 * 36] * n_kf, world)
+    sizes = [p.end - p.first for p in plans]
+    assert sum(sizes) == n_kf and 0 in sizes, sizes
+    owner = {g: r for r, p in enumerate(plans) for g in range(p.first, p.end)}
+    assert any(owner[j] - owner[i] > 1 or (owner[j] > owner[i] and 0 in sizes[owner[i] + 1:owner[j]])
+               for i in range(n_kf) for j in nbrs[i] if j > i), "no edge jumps a rank"
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, n_kf), nprocs=world, join=True)
+    want = oracle.fuse(frames, oracle.default_params(**PARAMS))
+    got = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    assert int(np.load(tmp_path / "total.npy")[0]) == want.key.shape[0] == len(got) > 0
+    for r in range(world):
+        part = np.load(tmp_path / f"rank{r}.npy")
+        assert (part_of(part["key"], world) == r).all()
+    got = got[np.argsort(got["key"], kind="stable")]
+    wk = pack_key(want.key)
+    wo = np.argsort(wk, kind="stable")
+    assert np.array_equal(got["key"], wk[wo]) and np.array_equal(got["tag"], want.tag[wo])
+    for ax, name in enumerate("xyz"):
+        assert np.array_equal(got[name], want.xyz[wo, ax])
 
 
 def test_oracle_helper_is_consistent():

@@ -37,12 +37,21 @@ def test_no_alloc_partition_counts_match_the_allocating_entry_point():
     assert got == want and sum(got) == n_small
     # and once more on the first ctx with another part count
     assert big.partition_counts_noalloc(7) == big.partition_counts(7)
+    # "allocates nothing": the device's free memory is the same before and after a burst of calls (hipMemGetInfo; a
+    # hipMalloc of any size would take at least one allocation granule from it)
+    import torch
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    for parts in (1, 3, 64, 1024, 2):
+        small.partition_counts_noalloc(parts)
+        big.partition_counts_noalloc(parts)
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after == free_before, (free_before, free_after)
     # beyond the static array's size: a clear error, nothing written
     with pytest.raises(fusion.FusionError) as e:
         big.partition_counts_noalloc(1025)
     assert e.value.code == fusion.SFM_E_CAPACITY and "1024" in str(e.value)
     # the allocating entry point is unchanged: it still arms export_records
-    import torch
     n = sum(big.partition_counts(4))
     buf = torch.empty(max(n, 1) * fusion.SFM_RECORD_BYTES, dtype=torch.uint8, device="cuda")
     big.export_records(buf.data_ptr(), n * fusion.SFM_RECORD_BYTES)

@@ -3,7 +3,8 @@
 #   tools/profile_pass.sh <tag> kt            kernel trace + stats
 #   tools/profile_pass.sh <tag> fetch|write   one --pmc pass (FETCH_SIZE / WRITE_SIZE), as MI355X_MICROARCH.md prescribes
 #   tools/profile_pass.sh <tag> valu          one --pmc pass of SQ instruction counters (VALU-issue floor of the chain kernel)
-# Output: gpurun_out/<tag>_<pass>/ ; then run tools/profile_summary.py <tag> (CPU side is fine).
+# BENCH_ARGS="--two-phase [--workload ...]" profiles that bench command instead (verdict_kernel + accept_chain_kernel).
+# Output: gpurun_out/<tag>_<pass>/ ; then run tools/profile_summary.py <tag> [--two-phase] [--workload W] (CPU side is fine).
 tag=$1; pass=$2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 case $pass in
@@ -13,7 +14,7 @@ case $pass in
   valu)  opts="--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; steps="--steps 1 --warmup 0" ;;
   *) echo "unknown pass $pass"; exit 2 ;;
 esac
-timeout -s KILL 200 rocprofv3 $opts --output-format csv -d gpurun_out/${tag}_${pass} -- python3 bench.py $steps --no-cpu-baseline > gpurun_out/${tag}_${pass}.log 2>&1
+timeout -s KILL 200 rocprofv3 $opts --output-format csv -d gpurun_out/${tag}_${pass} -- python3 bench.py $steps --no-cpu-baseline $BENCH_ARGS > gpurun_out/${tag}_${pass}.log 2>&1
 rc=$?
 grep -c . gpurun_out/${tag}_${pass}/*/*.csv 2>/dev/null | tail -4
 echo "rocprofv3 exit code $rc"

@@ -7,7 +7,9 @@ import json
 import sys
 
 tag = sys.argv[1]
-out = {"tag": tag, "workload": "c2_500kf_640x480_1cm", "kernels": {}}
+two_phase = "--two-phase" in sys.argv[2:]
+workload = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "c2_500kf_640x480_1cm"
+out = {"tag": tag, "workload": workload, "bench_args": "--two-phase" if two_phase else "", "kernels": {}}
 f = glob.glob(f"gpurun_out/{tag}_kt/*/*kernel_stats.csv")[0]
 for r in csv.DictReader(open(f)):
     if "sfm::" in r["Name"] or "rocclr" in r["Name"]:
@@ -27,6 +29,8 @@ for name in ("fetch", "write"):
 out["pmc"] = pmc
 # the dominant kernel: the persistent chain kernel, or the observe kernel of the fallback pair
 k = "sfm::fuse_chain_kernel" if "sfm::fuse_chain_kernel" in pmc["fetch"] else "sfm::observe_frame_kernel"
+if two_phase:
+    k = "sfm::accept_chain_kernel"
 short = k.split("::")[1]
 fetch_kb = pmc["fetch"][k]["kb_per_launch"]
 write_kb = pmc["write"][k]["kb_per_launch"]
@@ -38,6 +42,12 @@ out["dominant_kernel"] = short
 out[short + "_hbm_bytes_per_launch"] = hbm
 out[short + "_fetch_raw_bytes_per_launch"] = fetch_kb * 1024.0
 out[short + "_write_bytes_per_launch"] = write_kb * 1024.0
+if two_phase:  # phase A as well: one verdict_kernel launch per 32 keyframes
+    for kk in pmc["fetch"]:
+        if "verdict_kernel" in kk:
+            out["verdict_kernel_hbm_bytes_per_launch"] = (2.0 * pmc["fetch"][kk]["kb_per_launch"] + pmc["write"][kk]["kb_per_launch"]) * 1024.0
+            out["verdict_kernel_fetch_raw_bytes_per_launch"] = pmc["fetch"][kk]["kb_per_launch"] * 1024.0
+            out["verdict_kernel_write_bytes_per_launch"] = pmc["write"][kk]["kb_per_launch"] * 1024.0
 # optional: SQ instruction counters of the same command (tools/profile_pass.sh <tag> valu) and the micro-benchmarks
 # (gpurun_out/<tag>_valu_bench.txt, <tag>_barrier_bench.txt) -> profiles/bounds_latest.json, read by bench.py for
 # roofline.fp64 and roofline.chain
@@ -54,6 +64,9 @@ if vf:
     out["sq"] = {kname: dict(launches=launches[kname], **{c: v / max(1, launches[kname]) for c, v in cs.items()})
                  for kname, cs in agg.items()}
     bounds = {"workload": out["workload"], "tag": tag, "kernel": short}
+    if two_phase:
+        bounds = None
+if vf and bounds is not None:
     sq = out["sq"].get(k)
     if sq:
         # CDNA4: a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles, FP64 fma/mul/add included
@@ -93,5 +106,5 @@ json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 json.dump({"workload": out["workload"], "tag": tag, "hbm_bytes_per_launch": hbm,
            "kernel": short,
            "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of the dominant kernel, separate --pmc passes"},
-          open("profiles/traffic_latest.json", "w"), indent=1)
+          open("profiles/traffic_two_phase.json" if two_phase else "profiles/traffic_latest.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
