@@ -45,6 +45,18 @@
 #ifndef SFM_DIAG_ACC_NOREC
 #define SFM_DIAG_ACC_NOREC 0    // diagnostic only (wrong cloud): accept_chain_kernel writes tags without reading or writing the fused points
 #endif
+#ifndef SFM_FIN_ROT
+#define SFM_FIN_ROT 0        // fuse_chain_kernel: chunk j of a round is fused by wave (j + SFM_FIN_ROT) mod 16 (4, 8: measured slower)
+#endif
+#ifndef SFM_WAIT_THREAD
+// Who does what in a fuse_chain_kernel workgroup (profiles/r03_ab_wave_roles.txt, C2): the waves that fuse (0 .. chunks-1)
+// should neither wait for the arrival atomic's return nor poll.  Arrival from wave 8, polling from wave 15: 7.46 against
+// 7.60 ms with both on thread 0 (arrival on waves 5 / 15: 7.63 / 7.55; polling on waves 7 / 8: 7.46 / 7.59).
+#define SFM_WAIT_THREAD 960  // the thread that polls the barrier flag
+#endif
+#ifndef SFM_ARRIVE_THREAD
+#define SFM_ARRIVE_THREAD 512  // the thread that makes the barrier arrival (and waits for its atomic's return)
+#endif
 #ifndef SFM_STAMPS
 #define SFM_STAMPS 0  // diagnostic build only (tools/chain_stamps.py): adds fuse_chain_kernel_stamps, thread-0 phase timestamps of one launch
 #endif
@@ -1318,7 +1330,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
         SFM_CSTAMP(0);
         if (f > a.f0) {
             // every workgroup arrived after keyframe f-1 (below); its mask stores are out
-            if (threadIdx.x == 0) s_misc[1] = chain_wait(a.bar, f - a.f0, G, a.timeout_ticks, a.abort_all) ? 1u : 0u;
+            if (threadIdx.x == SFM_WAIT_THREAD) s_misc[1] = chain_wait(a.bar, f - a.f0, G, a.timeout_ticks, a.abort_all) ? 1u : 0u;
             __syncthreads();
             if (s_misc[1] == 0u) {  // workgroup-uniform
                 err |= kErrBarrier;
@@ -1393,7 +1405,11 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                     // waits for the barrier arrival's atomic to return, and the first waves have the second segment of
                     // the next keyframe's preparation and (K dividing 16) one item more in step B -- the workgroup is
                     // as late for the next keyframe as its busiest wave
+#if SFM_FIN_ROT
+                    const unsigned wf = (w + (unsigned)kChainWaves - SFM_FIN_ROT) % (unsigned)kChainWaves;
+#else
                     const unsigned wf = SFM_FIN_TOP ? (unsigned)kChainWaves - 1u - w : w;
+#endif
                     const bool fin = wf < rc;
                     const uint32_t cf = c0 + wf;
                     const uint32_t n_in = fin ? min(n - cf * kWave, (uint32_t)kWave) : 0u;
@@ -1432,7 +1448,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // my mask stores are acknowledged (write-through)
                         __syncthreads();
-                        if (threadIdx.x == 0) chain_arrive(a.bar, G, f - a.f0 + 1);
+                        if (threadIdx.x == SFM_ARRIVE_THREAD) chain_arrive(a.bar, G, f - a.f0 + 1);
                         arrived = true;
                         SFM_CSTAMP(6);
                     }
@@ -1523,7 +1539,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (threadIdx.x == 0) chain_arrive(a.bar, G, f - a.f0 + 1);
+                if (threadIdx.x == SFM_ARRIVE_THREAD) chain_arrive(a.bar, G, f - a.f0 + 1);
                 SFM_CSTAMP(6);
             }
             // while the others arrive: pull the next keyframe's neighbour descriptions into this
