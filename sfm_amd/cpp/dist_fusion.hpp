@@ -36,7 +36,7 @@ struct RankPlan {
 // Relative cost of a keyframe (per pixel) as rank 0's fused chain, as a later rank's phase A (verdicts) and as its
 // phase B (accept chain), measured on one MI355X.  Only the ratios matter, and only for speed.
 struct SplitCost {
-    double fused = 39.0, verdict = 42.0, accept = 14.3;
+    double fused = 38.2, verdict = 42.3, accept = 12.8;
     bool equal_blocks = false;
 };
 

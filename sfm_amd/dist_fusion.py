@@ -65,7 +65,7 @@ def shard_components(nbrs: Sequence[Sequence[int]], weights: Sequence[int], worl
 # Relative cost of a keyframe (per pixel) in the three roles a block can play, measured on one MI355X on the C3
 # workload: fused chain on rank 0, phase A (mask-independent verdicts) and phase B (accept
 # chain) on the later ranks.  Only the ratios matter, and only for speed: any split is exact.
-PIPELINE_COST = (39.0, 42.0, 14.3)
+PIPELINE_COST = (38.2, 42.3, 12.8)
 
 
 def block_shares(world: int, cost=PIPELINE_COST) -> list:
