@@ -719,12 +719,12 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
             const char *sg = std::getenv("SFM_STAMP_GROUP");
             const bool stamp_this = sg && (size_t)std::atoi(sg) == g && c->chain_xcd && !c->chain_coop;
             if (stamp_this) {
-                const size_t bytes = (size_t)kGroup * c->n_cu * 16 * 8;
+                const size_t bytes = (size_t)kGroup * c->n_cu * kStampSlots * 8;
                 if (!d_cstamps) (void)hipMalloc(&d_cstamps, bytes);
                 (void)hipMemsetAsync(d_cstamps, 0, bytes, sa);
                 ca.stamps = d_cstamps;
                 c->stamp_ptr = d_cstamps;
-                c->stamp_n = (size_t)kGroup * c->n_cu * 16;
+                c->stamp_n = (size_t)kGroup * c->n_cu * kStampSlots;
             }
 #else
             const bool stamp_this = false;

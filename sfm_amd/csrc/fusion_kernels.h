@@ -45,6 +45,9 @@
 #ifndef SFM_DIAG_ACC_NOREC
 #define SFM_DIAG_ACC_NOREC 0    // diagnostic only (wrong cloud): accept_chain_kernel writes tags without reading or writing the fused points
 #endif
+#ifndef SFM_PREP_FLIP
+#define SFM_PREP_FLIP 0
+#endif
 #ifndef SFM_FIN_ROT
 #define SFM_FIN_ROT 0        // fuse_chain_kernel: chunk j of a round is fused by wave (j + SFM_FIN_ROT) mod 16 (4, 8: measured slower)
 #endif
@@ -995,12 +998,22 @@ struct ChainArgs {
 
 // Phase timestamps of thread 0 (tools/chain_stamps.py); compiled into the diagnostic instantiation only
 // (fuse_chain_kernel_stamps, -DSFM_STAMPS=1 builds): the production kernels carry none of it.
+constexpr int kStampSlots = 48;  // per keyframe and workgroup: 16 of thread 0, 16 + 16 per wave
 template <bool STAMPS>
 __device__ __forceinline__ void chain_stamp(const ChainArgs &a, uint32_t f, int i, unsigned long long v = ~0ull)
 {
     if (STAMPS) {
         if (a.stamps && threadIdx.x == 0)
-            a.stamps[((size_t)(f - a.f0) * gridDim.x + blockIdx.x) * 16 + i] = v == ~0ull ? __builtin_amdgcn_s_memrealtime() : v;
+            a.stamps[((size_t)(f - a.f0) * gridDim.x + blockIdx.x) * kStampSlots + i] = v == ~0ull ? __builtin_amdgcn_s_memrealtime() : v;
+    }
+}
+// ... and one per wave (slots 16 + w and 32 + w): when wave w finished a keyframe's work / left step B
+template <bool STAMPS>
+__device__ __forceinline__ void chain_wave_stamp(const ChainArgs &a, uint32_t f, int base, unsigned w)
+{
+    if (STAMPS) {
+        if (a.stamps && lane_id() == 0)
+            a.stamps[((size_t)(f - a.f0) * gridDim.x + blockIdx.x) * kStampSlots + base + w] = __builtin_amdgcn_s_memrealtime();
     }
 }
 #define SFM_CSTAMP(i) chain_stamp<STAMPS>(a, f, (i))
@@ -1164,7 +1177,9 @@ __device__ __forceinline__ void chain_prepare(const FrameDev &F, const DevParams
     uint32_t dv[kChainSegs];
 #pragma unroll
     for (int u = 0; u < kChainSegs; u++) {
-        const uint32_t i = i0 + (uint32_t)u * kChainWaves + w;
+        // (SFM_PREP_FLIP: odd segments are dealt from the last wave down, so that a pass's last, partly filled segment
+        // row lands on the waves that do not fuse)
+        const uint32_t i = i0 + (uint32_t)u * kChainWaves + ((SFM_PREP_FLIP && (u & 1)) ? (uint32_t)kChainWaves - 1u - w : w);
         const uint32_t pr = i * (kWave / kPiece) + lane / kPiece;
         const uint32_t piece = chain_piece<XCD8>(pr, b, G);
         r.pixel[u] = piece * kPiece + lane % kPiece;
@@ -1328,6 +1343,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
     chain_prepare<XCD8>(frames[a.f0], P, 0, w, lane, b, G, pre, err);
     for (uint32_t f = a.f0; f < a.f1 && !aborted; f++) {
         SFM_CSTAMP(0);
+        chain_wave_stamp<STAMPS>(a, f, 16, w);  // this wave is ready for keyframe f (its fusion and preparation are done)
         if (f > a.f0) {
             // every workgroup arrived after keyframe f-1 (below); its mask stores are out
             if (threadIdx.x == SFM_WAIT_THREAD) s_misc[1] = chain_wait(a.bar, f - a.f0, G, a.timeout_ticks, a.abort_all) ? 1u : 0u;
@@ -1423,6 +1439,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                     else
                         chain_items<false>(nbp, P, K, rc, c0, n, w, lane, s_pw, s_obs, s_hit, s_kept, cnt_now, c_gather, err);
                     if (threadIdx.x == 0 && c0 == 0) *reinterpret_cast<unsigned long long *>(s_misc + 2) = res_base;
+                    if (c0 == 0) chain_wave_stamp<STAMPS>(a, f, 32, w);  // this wave's items of the first round are done
                     __syncthreads();
                     SFM_CSTAMP(3);
                     // ---- C: every wave scatters the masks of its own items (:152-154) ...

@@ -12,8 +12,9 @@ env = dict(os.environ, SFM_FUSION_LIB=os.path.abspath(os.environ.get("SFM_STAMPS
 subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + extra, env=env,
                check=True, stdout=subprocess.DEVNULL)
 raw = np.fromfile(out, dtype=np.uint64).astype(np.int64)
-G = raw.size // (32 * 16)
-s = raw.reshape(32, G, 16)
+SLOTS = 48   # kStampSlots: 16 of thread 0, then 16 + 16 per wave
+G = raw.size // (32 * SLOTS)
+s = raw.reshape(32, G, SLOTS)
 t0 = s[0, :, 0].min()
 names = ["frame top", "barrier passed", "A done (survivors in LDS)", "B done (first round)", "C done (last round)",
          "rounds done", "arrived", None, "C: decided", "C: masks issued", "C: sums done", "C: key done", "C: record issued"]
@@ -29,6 +30,21 @@ for f in (1, 2, 8, 16, 30):
         col = col[fr[:, i] > 0]
         if len(col):
             print("   %-28s min %6.2f  p50 %6.2f  max %6.2f" % (n, col.min(), np.percentile(col, 50), col.max()))
+# per wave (fuse_chain_kernel only): when wave w left step B's first round, and when it was ready for the NEXT keyframe
+# (fusion and preparation done), relative to its workgroup's pass of the barrier (thread 0, slot 1)
+if s[:, :, 16:48].any():
+    for f in (2, 8, 16):
+        ref = s[f][:, 1:2]
+        bdone = (s[f][:, 32:48] - ref) / 100.0
+        ready = (s[f + 1][:, 16:32] - ref) / 100.0
+        print("keyframe +%d, per wave 0..15, median over workgroups (us after the workgroup passed the barrier):" % f)
+        print("   step B done        " + " ".join("%5.1f" % np.median(bdone[:, w]) for w in range(16)))
+        print("   ready for the next " + " ".join("%5.1f" % np.median(ready[:, w]) for w in range(16)))
+        late = ready.argmax(axis=1)
+        print("   the workgroup's last wave to be ready is wave: " + " ".join("%d:%d" % (w, (late == w).sum()) for w in range(16)))
+        nxt = (s[f + 1][:, 1] - s[f][:, 1]) / 100.0
+        print("   workgroup's own period %.2f us median; last wave ready %.2f us, next barrier passed %.2f us after this one (medians)" % (
+            np.median(nxt), np.median(ready.max(axis=1)), np.median(nxt)))
 per_frame = np.diff(s[:, :, 1].min(axis=1)) / 100.0
 print("per-keyframe period (first workgroup past the barrier): mean %.2f us  min %.2f  max %.2f" % (
     per_frame[1:].mean(), per_frame[1:].min(), per_frame[1:].max()))
