@@ -965,6 +965,10 @@ __global__ __launch_bounds__(kMaxWaves * kWave) SFM_OBSERVE_OCC void observe_fra
 
 constexpr int kChainWaves = 16;
 constexpr int kChainThreads = kChainWaves * kWave;
+#ifndef SFM_FUSE_RESERVED
+#define SFM_FUSE_RESERVED 0  // fuse_chain_kernel: the first N waves own no pixels of step A (they finish the chunks); 0: every wave does
+#endif
+constexpr int kChainPrepWaves = kChainWaves - SFM_FUSE_RESERVED;  // waves that own pixels of step A
 constexpr int kChainSegs = 2;                                    // segments per wave and pass
 constexpr int kChainSurv = 1024;                                 // survivors per batch (LDS); a pass with more runs in batches
 constexpr int kChainMaxItems = 64;                               // (chunk, neighbour) slots in LDS
@@ -1179,7 +1183,12 @@ __device__ __forceinline__ void chain_prepare(const FrameDev &F, const DevParams
     for (int u = 0; u < kChainSegs; u++) {
         // (SFM_PREP_FLIP: odd segments are dealt from the last wave down, so that a pass's last, partly filled segment
         // row lands on the waves that do not fuse)
+#if SFM_FUSE_RESERVED
+        // waves 0 .. SFM_FUSE_RESERVED-1 own no pixels (they fuse); a slot beyond `slots` marks "none"
+        const uint32_t i = w < (unsigned)SFM_FUSE_RESERVED ? 0xFFFFFF00u : i0 + (uint32_t)u * kChainPrepWaves + (w - (unsigned)SFM_FUSE_RESERVED);
+#else
         const uint32_t i = i0 + (uint32_t)u * kChainWaves + ((SFM_PREP_FLIP && (u & 1)) ? (uint32_t)kChainWaves - 1u - w : w);
+#endif
         const uint32_t pr = i * (kWave / kPiece) + lane / kPiece;
         const uint32_t piece = chain_piece<XCD8>(pr, b, G);
         r.pixel[u] = piece * kPiece + lane % kPiece;
@@ -1363,7 +1372,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
         // masks are only ever read of keyframes still to come: the scatter skips the others
         if (threadIdx.x < K)
             s_nbmask[threadIdx.x] = nbp[threadIdx.x].order > F.order ? nbp[threadIdx.x].mask : nullptr;
-        for (uint32_t i0 = 0; i0 < slots; i0 += kChainWaves * kChainSegs) {
+        for (uint32_t i0 = 0; i0 < slots; i0 += kChainPrepWaves * kChainSegs) {
             // A pass is tried whole (part 0); when more than kChainSurv of its pixels survive (only
             // the first keyframes of a sequence), it is redone one segment per wave at a time
             // (parts 1..kChainSegs), which always fits.
@@ -1460,7 +1469,7 @@ __device__ __forceinline__ void fuse_chain_body(const FrameDev *__restrict__ fra
                     // The barrier only orders the mask stores.  After the last scatter of the keyframe the
                     // workgroup arrives at once, and forms its fused points while the others arrive:
                     // the fusion below is off the keyframe chain's critical path.
-                    if (f + 1 < a.f1 && c0 + R >= chunks && i0 + kChainWaves * kChainSegs >= slots &&
+                    if (f + 1 < a.f1 && c0 + R >= chunks && i0 + kChainPrepWaves * kChainSegs >= slots &&
                         (part == 0 || part == (uint32_t)kChainSegs)) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // my mask stores are acknowledged (write-through)

@@ -16,6 +16,63 @@ def twist(se3):
     return M
 
 
+def sophus_exp_py(se3):
+    """A second restatement of Sophus::SE3d::exp(v).matrix() and of the rigid inverse, in plain Python floats, written
+    from Sophus' published formulas (so3.hpp expAndTheta, se3.hpp exp) and Eigen's Quaternion::toRotationMatrix,
+    separately from the library's C code: (T, T_inv) as 4x4 arrays.  Sophus itself is not in this image."""
+    import math
+    ux, uy, uz, wx, wy, wz = (float(x) for x in se3)
+    theta_sq = wx * wx + wy * wy + wz * wz
+    eps = 1e-10
+    if theta_sq < eps * eps:
+        theta = 0.0
+        po4 = theta_sq * theta_sq
+        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * po4
+        real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * po4
+    else:
+        theta = math.sqrt(theta_sq)
+        half = 0.5 * theta
+        imag = math.sin(half) / theta
+        real = math.cos(half)
+    qw, qx, qy, qz = real, imag * wx, imag * wy, imag * wz
+    tx, ty, tz = 2.0 * qx, 2.0 * qy, 2.0 * qz
+    twx, twy, twz = tx * qw, ty * qw, tz * qw
+    txx, txy, txz = tx * qx, ty * qx, tz * qx
+    tyy, tyz, tzz = ty * qy, tz * qy, tz * qz
+    R = [[1.0 - (tyy + tzz), txy - twz, txz + twy],
+         [txy + twz, 1.0 - (txx + tzz), tyz - twx],
+         [txz - twy, tyz + twx, 1.0 - (txx + tyy)]]
+    if abs(theta) < eps:
+        V = [row[:] for row in R]
+    else:
+        Om = [[0.0, -wz, wy], [wz, 0.0, -wx], [-wy, wx, 0.0]]
+        Om2 = [[Om[i][0] * Om[0][j] + Om[i][1] * Om[1][j] + Om[i][2] * Om[2][j] for j in range(3)] for i in range(3)]
+        a = (1.0 - math.cos(theta)) / theta_sq
+        b = (theta - math.sin(theta)) / (theta_sq * theta)
+        V = [[(1.0 if i == j else 0.0) + a * Om[i][j] + b * Om2[i][j] for j in range(3)] for i in range(3)]
+    t = [V[i][0] * ux + V[i][1] * uy + V[i][2] * uz for i in range(3)]
+    T = np.eye(4)
+    Ti = np.eye(4)
+    for i in range(3):
+        for j in range(3):
+            T[i, j] = R[i][j]
+            Ti[i, j] = R[j][i]
+        T[i, 3] = t[i]
+        Ti[i, 3] = -(R[0][i] * t[0] + R[1][i] * t[1] + R[2][i] * t[2])
+    return T, Ti
+
+
+def test_the_library_and_the_python_restatement_agree_bit_for_bit():
+    rng = np.random.default_rng(11)
+    cases = [np.concatenate([rng.normal(0, 3.0, 3), rng.normal(0, 1.2, 3)]) for _ in range(300)]
+    cases += [np.array([0.3, -0.1, 0.7, w, -w / 2, w / 3]) for w in (0.0, 1e-12, 9.9e-11, 1.1e-10, 1e-8, 1e-5)]
+    for se3 in cases:
+        T, Ti = fusion.se3_exp(se3)
+        Tp, Tip = sophus_exp_py(se3)
+        assert np.array_equal(T.view(np.uint64), Tp.view(np.uint64)), se3
+        assert np.array_equal(Ti.view(np.uint64), Tip.view(np.uint64)), se3
+
+
 def test_known_answers():
     T, Ti = fusion.se3_exp([1.5, -2.0, 0.25, 0, 0, 0])              # pure translation
     assert np.array_equal(T, np.array([[1, 0, 0, 1.5], [0, 1, 0, -2.0], [0, 0, 1, 0.25], [0, 0, 0, 1.0]]))
@@ -58,6 +115,7 @@ def test_add_keyframe_se3_equals_add_keyframe_with_the_converted_matrices():
     frames = seq.frame_dicts()
     gp = fusion.default_params(voxel_size=30.0, T_dist=500.0)
     clouds = []
+    se3s = []
     for use_se3 in (True, False):
         ctx = fusion.FusionContext(gp)
         for f in frames:
@@ -69,6 +127,7 @@ def test_add_keyframe_se3_equals_add_keyframe_with_the_converted_matrices():
             Vm = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (th - np.sin(th)) / th ** 3 * Om @ Om
             se3 = np.concatenate([np.linalg.solve(Vm, f["T_kw"][:3, 3]), rv])
             if use_se3:
+                se3s.append(se3)
                 ctx.add_keyframe_se3(f["depth"], f["bgr"], f["K"], se3)
             else:
                 T_kw, T_wk = fusion.se3_exp(se3)
@@ -81,3 +140,14 @@ def test_add_keyframe_se3_equals_add_keyframe_with_the_converted_matrices():
     assert clouds[0][2].shape[0] > 500
     for a, b in zip(*clouds):
         assert np.array_equal(a, b)
+    # ... and against the ORACLE fed with the matrices of the independent Python restatement of Sophus' formulas
+    # (the comparison above is the HIP path against itself)
+    from oracle import oracle
+    ref = []
+    for f, se3 in zip(frames, se3s):
+        T_kw, T_wk = sophus_exp_py(se3)
+        ref.append(dict(f, T_kw=T_kw, T_wk=T_wk))
+    want = oracle.fuse(ref, oracle.default_params(voxel_size=30.0, T_dist=500.0))
+    xyz, bgr, key, tag = clouds[0]
+    assert np.array_equal(key, want.key) and np.array_equal(tag, want.tag) and np.array_equal(bgr, want.bgr)
+    assert np.array_equal(xyz.view(np.uint64), want.xyz.view(np.uint64))
