@@ -237,8 +237,21 @@ int sfm_fusion_precompute(sfm_fusion_ctx *ctx);
  * to back, device memory.  Dropped by set_active_range, add_keyframe, set_neighbors and clear_imported_masks. */
 int sfm_fusion_import_masks(sfm_fusion_ctx *ctx, uint32_t first, uint32_t count, const void *src_dev, uint64_t bytes);
 int sfm_fusion_clear_imported_masks(sfm_fusion_ctx *ctx);
-/* After sfm_fusion_run: the masks of keyframes [first, first+count) as the run left them, same packing. */
+/* After sfm_fusion_run (or sfm_fusion_run_chain): the masks of keyframes [first, first+count) as the run left them,
+ * same packing. */
 int sfm_fusion_export_masks(sfm_fusion_ctx *ctx, uint32_t first, uint32_t count, void *dst_dev, uint64_t bytes);
+/* sfm_fusion_run in two halves, for a rank that has successors waiting.  The frame loop (:48-52) and the voxel filter
+ * behind it (:54-58) run on two streams; the masks are final when the frame loop ends, while the filter of the last
+ * keyframe groups still runs (on the 2000-keyframe workload the filter is the longer of the two: 38 ms against 22).
+ * sfm_fusion_run_chain launches the whole run and returns when the frame loop has finished: export_masks is allowed
+ * from then on, nothing else that reads the result is.  sfm_fusion_finish waits for the rest and completes the run
+ * exactly as sfm_fusion_run would have (same retries, same stats); sfm_fusion_run does the same.  Between the two
+ * calls every call that changes what a run computes (add_keyframe, set_neighbors, set_covisibility, set_active_range,
+ * import_masks, clear_imported_masks, precompute, set_key_range, set_global_order, merge) returns SFM_E_INVALID.
+ * A retry that sfm_fusion_finish has to make (list, table or key packing too small) recomputes the same masks.
+ * No reference counterpart. */
+int sfm_fusion_run_chain(sfm_fusion_ctx *ctx);
+int sfm_fusion_finish(sfm_fusion_ctx *ctx);
 
 const char *sfm_fusion_last_error(sfm_fusion_ctx *ctx);
 const char *sfm_fusion_version(void);

@@ -4,7 +4,7 @@
 //   1. every rank but the first computes its block's mask-independent verdicts (sfm_fusion_precompute) while its
 //      predecessors chain;
 //   2. a rank receives the visibility masks its predecessors left on its keyframes (ncclRecv, rank order), fuses its
-//      block (sfm_fusion_run), and sends the masks of later ranks' keyframes on (ncclSend);
+//      block (sfm_fusion_run_chain), and sends the masks of later ranks' keyframes on (ncclSend);
 //   3. voxel exchange: winners bucketed by owner = hash(voxel indices) mod N, counts and key ranges by ncclAllGather,
 //      48-byte records by grouped ncclSend/ncclRecv (every peer pair on its own xGMI link), sfm_fusion_merge.
 // The union of the ranks' clouds is bit-identical to DenseReconstruction::fuse() on one GPU.
@@ -194,7 +194,10 @@ public:
                 off += nbytes;
             }, px);
         }
-        check(sfm_fusion_run(ctx));
+        // a rank with successors hands its masks on as soon as the frame loop has finished; the voxel filter of its last
+        // keyframe groups runs on (second stream of the ctx) under the sends and is collected by sfm_fusion_finish
+        const bool split = !plan.sends.empty();
+        check(split ? sfm_fusion_run_chain(ctx) : sfm_fusion_run(ctx));
         for (const auto &[t, fr] : plan.sends) {
             std::uint64_t off = 0;
             for_runs(plan, fr, [&](std::uint32_t first, std::uint32_t count, std::uint64_t nbytes) {
@@ -209,6 +212,7 @@ public:
             nccl(ncclGroupEnd(), "ncclGroupEnd");
             hip(hipStreamSynchronize(stream), "sync");
         }
+        if (split) check(sfm_fusion_finish(ctx));
         // 3. voxel exchange
         std::vector<std::uint64_t> counts(world_);
         check(sfm_fusion_partition_counts(ctx, (std::uint32_t)world_, counts.data()));

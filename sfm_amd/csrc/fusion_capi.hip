@@ -152,6 +152,14 @@ struct sfm_fusion_ctx {
     // one allocation: Counters | cursors | stat shards (zeroed by a single memset per run)
     unsigned char *d_small = nullptr;
     HostCounters *h_small = nullptr;  // pinned
+    StatShard *h_chain = nullptr;     // pinned: the chain's stat shards | phase A's, read by sfm_fusion_run_chain
+    // a run split in two (sfm_fusion_run_chain, sfm_fusion_finish): the attempt in flight and its capacities
+    struct RunState {
+        bool launched = false;
+        uint64_t table_cap = 0, shard_cap = 0, out_cap = 0;
+        int attempt = 0, key_attempts = 0;
+    } rs;
+    bool have_masks = false;          // the chain of the run in flight has finished: the masks may be exported
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_init = nullptr, ev_b_done = nullptr;
     std::vector<hipEvent_t> gev;  // one per keyframe group
@@ -283,6 +291,12 @@ int fail(sfm_fusion_ctx *c, int code, const std::string &msg)
             return fail((c), e_ == hipErrorOutOfMemory ? SFM_E_NOMEM : SFM_E_HIP,            \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
+
+// the calls that change what a run computes are refused between sfm_fusion_run_chain and sfm_fusion_finish
+int run_in_flight(sfm_fusion_ctx *c)
+{
+    return fail(c, SFM_E_INVALID, "a run is in flight: call sfm_fusion_finish first");
+}
 
 int arena_alloc(sfm_fusion_ctx *c, size_t bytes, void **out)
 {
@@ -566,9 +580,12 @@ static inline bool div_trust()
 #endif
 }
 
-// One attempt with fixed capacities.  table_cap is a power of two.
-int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t out_cap, uint32_t *err_bits)
+// One attempt with fixed capacities, first half: every launch of the attempt, the keyframe chain on stream A and the
+// table kernels on stream B.  Nothing here waits for the device.  table_cap is a power of two.  *refused: the runtime
+// would not take the cooperative grid (both streams are idle again; the caller reruns with the kernel pair).
+int run_launch(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t out_cap, bool *refused)
 {
+    *refused = false;
     const size_t n = c->frames.size();
     const uint64_t list_cap = shard_cap * kListShards;
     if (shard_cap > 0xFFF00000ull)  // table_group_kernel walks a shard with 32-bit offsets (and a grid-sized stride)
@@ -577,7 +594,8 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     if ((rc = ensure(c, c->d_table, table_cap))) return rc;
     if ((rc = ensure(c, c->d_list_key, list_cap))) return rc;
     if ((rc = ensure(c, c->d_list_tag, list_cap))) return rc;
-    if ((rc = ensure(c, c->d_list_xyz, 3 * list_cap))) return rc;
+    // (with phase A's verdicts the fused points stay in the verdict records: finalize_kernel reads the winners there)
+    if (!c->have_verdicts && (rc = ensure(c, c->d_list_xyz, 3 * list_cap))) return rc;
     // + the unused chunk tails of table_group_kernel's waves: at most two chunks per wave and launch
     if ((rc = ensure(c, c->d_cand, list_cap + (uint64_t)((c->frames.size() + kGroup - 1) / kGroup) * c->table_wgs *
                                                   kListShards * 4 * 2 * kCandChunk))) return rc;
@@ -649,8 +667,9 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
     fa.cand = c->d_cand.p;
     fa.cand_end = c->d_cand_end.p;
     fa.frames = c->d_frames.p;
+    fa.verdicts = c->have_verdicts ? c->d_verdicts.p : nullptr;  // two-phase chain: the winners' points are in the verdict records
+    fa.v_first = (uint32_t)std::min<size_t>(c->act_first, n);
     fa.group = 0;
-    fa.pad = 0;
     fa.out_cap = out_cap;
     fa.ctr = dev_ctr(c);
     fa.out_xyz = c->d_out_xyz.p;
@@ -757,7 +776,7 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
                     (void)hipGetLastError();
                     HIP_TRY(c, hipStreamSynchronize(sa));
                     HIP_TRY(c, hipStreamSynchronize(sb));
-                    *err_bits = kErrBarrier;
+                    *refused = true;
                     return SFM_OK;
                 }
             } else {
@@ -846,6 +865,34 @@ int run_once(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t
 #endif
     HIP_TRY(c, hipEventRecord(c->ev[2], sa));
     HIP_TRY(c, hipEventRecord(c->ev_b_done, sb));
+    return SFM_OK;
+}
+
+// The chain's own error bits, read as soon as the chain has finished; the table kernels of the last groups may still
+// run on stream B (sfm_fusion_run_chain: the visibility masks are final here, and a rank of a sequence split hands
+// them on without waiting for its cloud).
+int chain_status(sfm_fusion_ctx *c, uint32_t *err_bits)
+{
+    hipStream_t sa = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->h_chain, dev_stat(c), sizeof(StatShard) * kStatShards, hipMemcpyDeviceToHost, sa));
+    HIP_TRY(c, hipMemcpyAsync(c->h_chain + kStatShards, dev_pa_stat(c), sizeof(StatShard) * kStatShards,
+                              hipMemcpyDeviceToHost, sa));
+    HIP_TRY(c, hipStreamSynchronize(sa));
+    uint32_t err = 0;
+    for (int s = 0; s < kStatShards; s++) err |= c->h_chain[s].err;
+    if (c->verdicts_ran)
+        for (int s = 0; s < kStatShards; s++)
+            if (c->h_chain[kStatShards + s].err & kErrDivRange) err |= kErrDivRangeA;
+    *err_bits = err;
+    return SFM_OK;
+}
+
+// Second half of an attempt: wait for both streams, read the counters back.
+int run_collect(sfm_fusion_ctx *c, uint64_t shard_cap, uint32_t *err_bits)
+{
+    const size_t n = c->frames.size();
+    const bool use_verdicts = c->verdicts_ran;
+    hipStream_t sa = c->stream;
     HIP_TRY(c, hipStreamWaitEvent(sa, c->ev_b_done, 0));
     HIP_TRY(c, hipEventRecord(c->ev[3], sa));
     HIP_TRY(c, hipMemcpyAsync(c->h_small, c->d_small, kSmallBytes, hipMemcpyDeviceToHost, sa));
@@ -988,6 +1035,7 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
         c->scratch = static_cast<unsigned long long *>(g_scratch_ptr[device]);
     }
     ok = ok && hipHostMalloc(&c->h_small, kSmallBytes, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_chain, 2 * kStatShards * sizeof(StatShard), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     for (int i = 0; ok && i < 2; i++) ok = hipEventCreate(&c->ev_pa[i]) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) == hipSuccess;
@@ -1024,6 +1072,7 @@ void sfm_fusion_destroy(sfm_fusion_ctx *c)
     release(c->d_out_bgr); release(c->d_group_end); release(c->d_cand_end);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->h_chain) (void)hipHostFree(c->h_chain);
     if (c->h_part) (void)hipHostFree(c->h_part);
     if (c->h_fcounts) (void)hipHostFree(c->h_fcounts);
     for (auto &e : c->ev)
@@ -1045,6 +1094,7 @@ int sfm_fusion_add_keyframe(sfm_fusion_ctx *c, uint32_t order_idx, int32_t W, in
                             const double T_kw[16], int mem_kind)
 {
     if (!c) return SFM_E_INVALID;
+    if (c->rs.launched) return run_in_flight(c);
     if (order_idx != c->frames.size())
         return fail(c, SFM_E_INVALID, "keyframes must be added in order 0,1,2,...");
     if (W < 0 || H < 0 || !K || !T_wk || !T_kw) return fail(c, SFM_E_INVALID, "bad keyframe argument");
@@ -1097,7 +1147,7 @@ int sfm_fusion_add_keyframe(sfm_fusion_ctx *c, uint32_t order_idx, int32_t W, in
     }
     c->frames.push_back(std::move(f));
     c->layout_dirty = true;
-    c->have_result = false;
+    c->have_result = c->have_masks = false;
     return SFM_OK;
 }
 
@@ -1176,12 +1226,13 @@ int sfm_fusion_add_keyframe_se3(sfm_fusion_ctx *c, uint32_t order_idx, int32_t W
 int sfm_fusion_set_neighbors(sfm_fusion_ctx *c, uint32_t order_idx, const uint32_t *nbr, uint32_t n)
 {
     if (!c) return SFM_E_INVALID;
+    if (c->rs.launched) return run_in_flight(c);
     if (order_idx >= c->frames.size()) return fail(c, SFM_E_INVALID, "unknown keyframe");
     if (n && !nbr) return fail(c, SFM_E_INVALID, "null neighbour list");
     c->frames[order_idx].nbrs.assign(nbr, nbr + n);
     c->frames[order_idx].selected = true;
     c->layout_dirty = true;
-    c->have_result = false;
+    c->have_result = c->have_masks = false;
     return SFM_OK;
 }
 
@@ -1190,6 +1241,7 @@ int sfm_fusion_set_covisibility(sfm_fusion_ctx *c, const uint32_t *edge_a, const
                                 uint32_t neighbor_min)
 {
     if (!c) return SFM_E_INVALID;
+    if (c->rs.launched) return run_in_flight(c);
     if (n_edges && (!edge_a || !edge_b || !edge_count)) return fail(c, SFM_E_INVALID, "null edge array");
     const size_t n = c->frames.size();
     for (uint64_t e = 0; e < n_edges; e++) {
@@ -1230,52 +1282,84 @@ int sfm_fusion_set_covisibility(sfm_fusion_ctx *c, const uint32_t *edge_a, const
         if (!f.selected) f.nbrs.clear();
     }
     c->layout_dirty = true;
-    c->have_result = false;
+    c->have_result = c->have_masks = false;
     return SFM_OK;
 }
 
-int sfm_fusion_run(sfm_fusion_ctx *c)
+namespace {
+// sfm_fusion_run and its two halves.  stop_after_chain: return as soon as the keyframe chain has finished without a
+// chain error (the masks are final; the table kernels still run); the next call goes on from there.
+int run_driver(sfm_fusion_ctx *c, bool stop_after_chain)
 {
-    if (!c) return SFM_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = c->frames.size();
-    for (size_t i = 0; i < n; i++)
-        for (uint32_t j : c->frames[i].nbrs) {
-            if (j >= n) return fail(c, SFM_E_INVALID, "neighbour index out of range");
-            if (j == i) return fail(c, SFM_E_INVALID, "a keyframe cannot be its own neighbour");
-        }
     int rc;
-    if (c->up_pending) {  // the images still in flight on the upload stream
-        HIP_TRY(c, hipEventRecord(c->ev_up, c->stream_up));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up, 0));
-        c->up_pending = false;
+    auto &rs = c->rs;
+    if (!rs.launched) {
+        for (size_t i = 0; i < n; i++)
+            for (uint32_t j : c->frames[i].nbrs) {
+                if (j >= n) return fail(c, SFM_E_INVALID, "neighbour index out of range");
+                if (j == i) return fail(c, SFM_E_INVALID, "a keyframe cannot be its own neighbour");
+            }
+        if (c->up_pending) {  // the images still in flight on the upload stream
+            HIP_TRY(c, hipEventRecord(c->ev_up, c->stream_up));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up, 0));
+            c->up_pending = false;
+        }
+        if (c->layout_dirty && (rc = build_layout(c))) return rc;
+        c->have_result = c->have_masks = false;
+        // keyframes with more neighbours than the fused kernels hold always take the two-phase chain
+        if ((c->big_k || (c->auto_precompute && c->chain)) && !c->have_verdicts && (rc = sfm_fusion_precompute(c))) return rc;
+        c->part_counts.clear();  // sfm_fusion_export_records needs counts of THIS run's cloud
+        // a fallback is not for life: after kChainRetryRuns runs on the kernel pair the chain kernel is tried again
+        // (three fallbacks in a ctx's life make it permanent: something else owns CUs of this device for good)
+        if (!c->chain && c->chain_off_runs > 0 && --c->chain_off_runs == 0 && c->chain_fallbacks < 3) c->chain = true;
     }
-    if (c->layout_dirty && (rc = build_layout(c))) return rc;
-    c->have_result = false;
-    // keyframes with more neighbours than the fused kernels hold always take the two-phase chain
-    if ((c->big_k || (c->auto_precompute && c->chain)) && !c->have_verdicts && (rc = sfm_fusion_precompute(c))) return rc;
-    c->part_counts.clear();  // sfm_fusion_export_records needs counts of THIS run's cloud
-    // a fallback is not for life: after kChainRetryRuns runs on the kernel pair the chain kernel is tried again
-    // (three fallbacks in a ctx's life make it permanent: something else owns CUs of this device for good)
-    if (!c->chain && c->chain_off_runs > 0 && --c->chain_off_runs == 0 && c->chain_fallbacks < 3) c->chain = true;
     const bool fixed_tab = c->prm.table_capacity != 0, fixed_list = c->prm.max_points != 0;
-    // Sizes: explicit, else what the previous run ended with, else a first guess that the
-    // retry loop below doubles until the run fits.
-    uint64_t shard_cap = fixed_list ? (c->prm.max_points + kListShards - 1) / kListShards
-                                    : std::max<uint64_t>(c->d_list_key.n / kListShards,
-                                                         std::max<uint64_t>(c->total_px / 4, 1 << 16) / kListShards);
-    uint64_t table_cap = fixed_tab ? pow2_at_least(c->prm.table_capacity)
-                                   : pow2_at_least(std::max<uint64_t>(c->d_table.n,
-                                                                      std::max<uint64_t>(c->total_px / 16, 1 << 16)));
-    // output slots: what the previous run ended with, else one per 16 pixels (C2 needs one per 97, the
-    // 5-mm C5 sample one per 21); the exact need is known after an overflowing run
-    uint64_t out_cap = std::max<uint64_t>(c->out_cap, std::max<uint64_t>(c->total_px / 16, 1 << 12));
+    if (!rs.launched) {
+        // Sizes: explicit, else what the previous run ended with, else a first guess that the
+        // retry loop below doubles until the run fits.
+        rs.shard_cap = fixed_list ? (c->prm.max_points + kListShards - 1) / kListShards
+                                  : std::max<uint64_t>(c->d_list_key.n / kListShards,
+                                                       std::max<uint64_t>(c->total_px / 4, 1 << 16) / kListShards);
+        rs.table_cap = fixed_tab ? pow2_at_least(c->prm.table_capacity)
+                                 : pow2_at_least(std::max<uint64_t>(c->d_table.n,
+                                                                    std::max<uint64_t>(c->total_px / 16, 1 << 16)));
+        // output slots: what the previous run ended with, else one per 16 pixels (C2 needs one per 97, the
+        // 5-mm C5 sample one per 21); the exact need is known after an overflowing run
+        rs.out_cap = std::max<uint64_t>(c->out_cap, std::max<uint64_t>(c->total_px / 16, 1 << 12));
+        rs.attempt = rs.key_attempts = 0;
+        c->key_scan = false;
+    }
+    uint64_t &shard_cap = rs.shard_cap, &table_cap = rs.table_cap, &out_cap = rs.out_cap;
+    int &key_attempts = rs.key_attempts;
     const uint64_t shard_max = c->total_px + kTile;  // every pixel live, all tiles in one shard
-    int key_attempts = 0;
-    c->key_scan = false;
-    for (int attempt = 0;; attempt++) {
+    for (;; rs.attempt++) {
+        const int attempt = rs.attempt;
         uint32_t err = 0;
-        if ((rc = run_once(c, table_cap, shard_cap, out_cap, &err))) return rc;
+        if (!rs.launched) {
+            bool refused = false;
+            if ((rc = run_launch(c, table_cap, shard_cap, out_cap, &refused))) return rc;
+            if (refused) {
+                err = kErrBarrier;
+            } else {
+                rs.launched = true;
+                if (stop_after_chain) {
+                    uint32_t cerr = 0;
+                    if ((rc = chain_status(c, &cerr))) return rc;
+                    if (!(cerr & (kErrBarrier | kErrDivRange | kErrDivRangeA))) {
+                        // every keyframe of the range has marked what it observed.  Whatever a later attempt may still
+                        // have to repeat (a full list or table, an unfit key packing), it computes the same masks.
+                        c->have_masks = true;
+                        return SFM_OK;
+                    }
+                }
+            }
+        }
+        if (rs.launched) {
+            rs.launched = false;
+            if ((rc = run_collect(c, shard_cap, &err))) return rc;
+        }
         const bool crowded = !err && !fixed_tab && c->h_small->ctr.table_used * 2 > table_cap;
         if (!err && !crowded) break;
         if (err & kErrDivRangeA) {
@@ -1406,13 +1490,36 @@ int sfm_fusion_run(sfm_fusion_ctx *c)
             st.fuse_kernel_launches++;
         }
     }
-    c->have_result = true;
+    c->have_result = c->have_masks = true;
     return SFM_OK;
+}
+
+}  // namespace
+
+int sfm_fusion_run(sfm_fusion_ctx *c)
+{
+    if (!c) return SFM_E_INVALID;
+    return run_driver(c, false);  // (after sfm_fusion_run_chain: the rest of that run)
+}
+
+int sfm_fusion_run_chain(sfm_fusion_ctx *c)
+{
+    if (!c) return SFM_E_INVALID;
+    if (c->rs.launched) return run_in_flight(c);
+    return run_driver(c, true);
+}
+
+int sfm_fusion_finish(sfm_fusion_ctx *c)
+{
+    if (!c) return SFM_E_INVALID;
+    if (!c->rs.launched) return fail(c, SFM_E_INVALID, "no run in flight: call sfm_fusion_run_chain first");
+    return run_driver(c, false);
 }
 
 int sfm_fusion_precompute(sfm_fusion_ctx *c)
 {
     if (!c) return SFM_E_INVALID;
+    if (c->rs.launched) return run_in_flight(c);
     HIP_TRY(c, hipSetDevice(c->device));
     int rc;
     if (c->up_pending) {
@@ -1501,12 +1608,13 @@ int sfm_fusion_precompute(sfm_fusion_ctx *c)
 int sfm_fusion_set_active_range(sfm_fusion_ctx *c, uint32_t first, uint32_t end)
 {
     if (!c) return SFM_E_INVALID;
+    if (c->rs.launched) return run_in_flight(c);
     if (first > end || end > c->frames.size())
         return fail(c, SFM_E_INVALID, "active range must satisfy first <= end <= number of keyframes added");
     c->act_first = first;
     c->act_end = end;
     c->layout_dirty = true;  // pixel totals (sizing, n_px) follow the range; imported masks are dropped with the layout
-    c->have_result = false;
+    c->have_result = c->have_masks = false;
     return SFM_OK;
 }
 
@@ -1526,6 +1634,7 @@ int mask_span(sfm_fusion_ctx *c, uint32_t first, uint32_t count, uint64_t bytes,
 int sfm_fusion_import_masks(sfm_fusion_ctx *c, uint32_t first, uint32_t count, const void *src_dev, uint64_t bytes)
 {
     if (!c) return SFM_E_INVALID;
+    if (c->rs.launched) return run_in_flight(c);
     int rc;
     if ((rc = mask_span(c, first, count, bytes, src_dev))) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1546,22 +1655,25 @@ int sfm_fusion_import_masks(sfm_fusion_ctx *c, uint32_t first, uint32_t count, c
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(s));  // the caller's buffer is free again on return
-    c->have_result = false;
+    c->have_result = c->have_masks = false;
     return SFM_OK;
 }
 
 int sfm_fusion_clear_imported_masks(sfm_fusion_ctx *c)
 {
     if (!c) return SFM_E_INVALID;
+    if (c->rs.launched) return run_in_flight(c);
     c->have_seed = false;
-    c->have_result = false;
+    c->have_result = c->have_masks = false;
     return SFM_OK;
 }
 
 int sfm_fusion_export_masks(sfm_fusion_ctx *c, uint32_t first, uint32_t count, void *dst_dev, uint64_t bytes)
 {
     if (!c) return SFM_E_INVALID;
-    if (!c->have_result) return fail(c, SFM_E_INVALID, "no result: call sfm_fusion_run first");
+    // (between sfm_fusion_run_chain and sfm_fusion_finish too: the chain has finished, stream A is idle, and the table
+    // kernels still running on stream B do not touch the masks)
+    if (!c->have_result && !c->have_masks) return fail(c, SFM_E_INVALID, "no result: call sfm_fusion_run first");
     int rc;
     if ((rc = mask_span(c, first, count, bytes, dst_dev))) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1586,6 +1698,7 @@ int sfm_fusion_set_profiling(sfm_fusion_ctx *c, int enable)
 int sfm_fusion_set_global_order(sfm_fusion_ctx *c, const uint32_t *order, uint32_t n)
 {
     if (!c) return SFM_E_INVALID;
+    if (c->rs.launched) return run_in_flight(c);
     if (n != c->frames.size() || (n && !order))
         return fail(c, SFM_E_INVALID, "global order must cover every keyframe");
     for (uint32_t i = 1; i < n; i++)
@@ -1607,6 +1720,7 @@ int sfm_fusion_get_key_range(sfm_fusion_ctx *c, int64_t lo[3], int64_t hi[3])
 int sfm_fusion_set_key_range(sfm_fusion_ctx *c, const int64_t lo[3], const int64_t hi[3])
 {
     if (!c || !lo || !hi) return SFM_E_INVALID;
+    if (c->rs.launched) return run_in_flight(c);
     KeyRangeDev nk;
     for (int a = 0; a < 3; a++) {
         nk.lo[a] = lo[a];
@@ -1746,6 +1860,7 @@ int sfm_fusion_export_records(sfm_fusion_ctx *c, void *dst_dev, uint64_t dst_byt
 int sfm_fusion_merge(sfm_fusion_ctx *c, const void *records_dev, uint64_t n)
 {
     if (!c || (n && !records_dev)) return SFM_E_INVALID;
+    if (c->rs.launched) return run_in_flight(c);
     HIP_TRY(c, hipSetDevice(c->device));
     int rc;
     const uint64_t table_cap = pow2_at_least(std::max<uint64_t>(2 * n, 1 << 16));

@@ -39,11 +39,8 @@
 // the chain beside it is its traffic per microsecond, which goes up.
 #define SFM_TABLE_MARK_CAS 1
 #endif
-#ifndef SFM_ACC_PREFETCH_REC
-#define SFM_ACC_PREFETCH_REC 0  // accept_chain_kernel: 1 = every pixel's fused point is read before the barrier opens (measured slower)
-#endif
 #ifndef SFM_DIAG_ACC_NOREC
-#define SFM_DIAG_ACC_NOREC 0    // diagnostic only (wrong cloud): accept_chain_kernel writes tags without reading or writing the fused points
+#define SFM_DIAG_ACC_NOREC 0    // diagnostic only (wrong cloud): accept_chain_kernel writes tags without reading or writing the voxel keys
 #endif
 #ifndef SFM_PREP_FLIP
 #define SFM_PREP_FLIP 0
@@ -1841,27 +1838,17 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
             // the loads are unconditional -- a lane without a pixel reads pixel 0, a missing neighbour slot the last
             // one -- and nothing looks at their values before the barrier: no wait is placed in front of it)
             uint32_t pixv[kAccIter], infov[kAccIter], h[kAccIter][4];
-            typedef unsigned long long ull2_t __attribute__((ext_vector_type(2)));
-            ull2_t r0[kAccIter], r1[kAccIter];
             bool inv[kAccIter];
             const uint32_t nl = V.n_later;
             const uint32_t ql = nl ? nl - 1u : 0u;
 #pragma unroll
             for (int j = 0; j < kAccIter; j++) {
-                r0[j] = r1[j] = ull2_t{0ull, 0ull};
                 pixv[j] = (((uint32_t)j * kAccDataWaves + dw) * G + b) * kWave + lane;
                 inv[j] = (uint32_t)j < mine && pixv[j] < npx;
                 const uint32_t pa = inv[j] ? pixv[j] : 0u;
                 infov[j] = mine ? (uint32_t)ldg(V.info + pa) : 0u;  // (uniform conditions: an empty keyframe has nothing to read)
 #pragma unroll
                 for (int q = 0; q < 4; q++) h[j][q] = (mine && nl) ? ldg(V.hits + (size_t)min((uint32_t)q, ql) * npx + pa) : kNoHit;
-#if SFM_ACC_PREFETCH_REC
-                if (mine) {  // ... and the pixel's fused point (valid where the verdict is positive; read for every pixel: dense)
-                    const VerdictRec *rp = V.rec + pa;
-                    r0[j] = *(const __attribute__((address_space(1))) ull2_t *)rp;
-                    r1[j] = *((const __attribute__((address_space(1))) ull2_t *)rp + 1);
-                }
-#endif
             }
             __syncthreads();  // B1
             if (s_go == 0u) {
@@ -1878,11 +1865,6 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                         infov[j] = (uint32_t)ldg(V.info + pa);
 #pragma unroll
                         for (int q = 0; q < 4; q++) h[j][q] = nl ? ldg(V.hits + (size_t)min((uint32_t)q, ql) * npx + pa) : kNoHit;
-#if SFM_ACC_PREFETCH_REC
-                        const VerdictRec *rp = V.rec + pa;
-                        r0[j] = *(const __attribute__((address_space(1))) ull2_t *)rp;
-                        r1[j] = *((const __attribute__((address_space(1))) ull2_t *)rp + 1);
-#endif
                     }
                 }
                 // mask == 0 (:100): every lane with a pixel asks for its own byte, whatever its verdict -- all the loads
@@ -1927,26 +1909,21 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                             if (acc[j] && s0 + (uint32_t)q < nl && h2[j][q] != kNoHit)
                                 mask_store_coherent(later_mask[s0 + q] + h2[j][q]);
                 }
-#if SFM_ACC_PREFETCH_REC
-                // (measured slower: 38 KB of fused points per workgroup and keyframe read ahead for every pixel, 4.65 against
-                // 4.15 ms per C2 run)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-                // the accepted pixels' fused points (cold, scattered reads; unconditional loads: their number is fixed),
-                // requested now so that their round trip runs under the marks' acknowledgement and the arrival ...
+                // the accepted pixels' voxel keys (cold, scattered 8-byte reads of the verdict records; unconditional loads:
+                // their number is fixed), requested now so that their round trip runs under the marks' acknowledgement and
+                // the arrival ...  (the fused point itself stays where verdict_kernel left it: finalize_kernel reads it
+                // through the tag, for the voxels' winners only -- one list entry is tag + key, 16 bytes instead of 40)
+                unsigned long long rk[kAccIter];
 #pragma unroll
-                for (int j = 0; j < kAccIter; j++) {
-                    const VerdictRec *rp = V.rec + ((acc[j] && !SFM_DIAG_ACC_NOREC) ? pixv[j] : 0u);
-                    r0[j] = *(const __attribute__((address_space(1))) ull2_t *)rp;
-                    r1[j] = *((const __attribute__((address_space(1))) ull2_t *)rp + 1);
-                }
+                for (int j = 0; j < kAccIter; j++)
+                    rk[j] = ldg(&V.rec[(acc[j] && !SFM_DIAG_ACC_NOREC) ? pixv[j] : 0u].key);
                 // ... but not in front of it: a wave's vector-memory operations complete in issue order, and the wait
-                // below leaves exactly the 2 * kAccIter loads just issued outstanding.  The barrier only orders the marks.
+                // below leaves exactly the kAccIter loads just issued outstanding.  The barrier only orders the marks.
+                // (Measured alternatives, profiles/r03_ab_accept_chain.txt: these loads behind the arrival 4.97 ms per C2
+                // run, every pixel's record read ahead of the barrier 4.65 ms, against 4.14 ms with whole records here.)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                static_assert(kAccIter == 4, "the counted wait names 2 * kAccIter loads");
-                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-#endif
+                static_assert(kAccIter == 4, "the counted wait names kAccIter loads");
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
                 __syncthreads();  // B2
                 __syncthreads();  // B3
                 // the accepted pixels' list entries, behind the arrival
@@ -1958,12 +1935,7 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                         if (rel < a.list.shard_cap) {
                             const unsigned long long idx = (unsigned long long)(b % kListShards) * a.list.shard_cap + rel;
                             a.list.tag[idx] = (infov[j] & kVKeyRange) ? kEmpty : (((unsigned long long)F.order << 32) | pixv[j]);
-                            if (!SFM_DIAG_ACC_NOREC) {
-                                a.list.key[idx] = r0[j].x;
-                                a.list.xyz[3 * idx + 0] = __longlong_as_double((long long)r0[j].y);
-                                a.list.xyz[3 * idx + 1] = __longlong_as_double((long long)r1[j].x);
-                                a.list.xyz[3 * idx + 2] = __longlong_as_double((long long)r1[j].y);
-                            }
+                            if (!SFM_DIAG_ACC_NOREC) a.list.key[idx] = rk[j];
                         } else {
                             err |= kErrListFull;
                         }
@@ -2186,7 +2158,11 @@ struct FinalizeArgs {
     // taken in stream order): this launch walks [cand_end[group-1], cand_end[group])
     const unsigned long long *cand_end;
     const FrameDev *frames;  // every keyframe of the ctx (device copy): the winners' colours are read here
-    uint32_t group, pad;
+    // two-phase chain: accept_chain_kernel leaves tag and key in the list; a winner's fused point is read where
+    // verdict_kernel left it (verdicts[keyframe - v_first].rec[pixel]).  nullptr: the point is in list.xyz.
+    const struct VerdictDev *verdicts;
+    uint32_t v_first;
+    uint32_t group;
     uint64_t out_cap;  // output slots; the counter keeps counting beyond (the host grows and reruns)
     Counters *ctr;
     // output (SoA, device)
@@ -2268,9 +2244,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
             if (o >= a.out_cap) {
                 atomicOr(&a.ctr->err, kErrOutFull);
             } else {
-                a.out_xyz[3 * o + 0] = a.list.xyz[3 * e[j] + 0];
-                a.out_xyz[3 * o + 1] = a.list.xyz[3 * e[j] + 1];
-                a.out_xyz[3 * o + 2] = a.list.xyz[3 * e[j] + 2];
+                if (a.verdicts) {  // wave-uniform
+                    const VerdictRec *r = a.verdicts[(uint32_t)(tag[j] >> 32) - a.v_first].rec + (uint32_t)tag[j];
+                    a.out_xyz[3 * o + 0] = r->x;
+                    a.out_xyz[3 * o + 1] = r->y;
+                    a.out_xyz[3 * o + 2] = r->z;
+                } else {
+                    a.out_xyz[3 * o + 0] = a.list.xyz[3 * e[j] + 0];
+                    a.out_xyz[3 * o + 1] = a.list.xyz[3 * e[j] + 1];
+                    a.out_xyz[3 * o + 2] = a.list.xyz[3 * e[j] + 2];
+                }
                 // colour of the source pixel (:170, features.cpp:76-80): the tag names keyframe and pixel
                 a.out_bgr[o] = ldg_u32_unaligned(a.frames[tag[j] >> 32].bgr + 3ull * (uint32_t)tag[j]) & 0xFFFFFFu;
                 a.out_key[o] = key[j];

@@ -168,11 +168,11 @@ def _runs(local_ids):
 class SequenceSplit:
     """One pass of the keyframe chain of ONE sequence over all ranks: receive the masks the earlier blocks left,
     fuse this rank's block, send the masks of later keyframes on.  `ctx` provides clear_imported_masks(),
-    import_masks(first, count, ptr, nbytes), run(), export_masks(first, count, ptr, nbytes) -- sfm_amd.fusion.
+    import_masks(first, count, ptr, nbytes), run() [or run_chain() + finish()], export_masks(first, count, ptr, nbytes) -- sfm_amd.fusion.
     FusionContext on a GPU, an oracle-backed stand-in in the CPU tests.  `px` maps a global keyframe to W*H.
     The mask buffers (device, and host staging where the backend is gloo) are made once per plan, here.
     After run(): `timing` = host-side milliseconds of the pass (phase_a_issue, wait = blocked in recv for the
-    predecessors' masks, import, run, send)."""
+    predecessors' masks, import, run = until the masks are final, send, finish = the rest of the run)."""
 
     def __init__(self, ctx, plan: RankPlan, px, rank: int, world: int, device, group=None, precompute=None):
         self.ctx, self.plan, self.px = ctx, plan, px
@@ -198,7 +198,7 @@ class SequenceSplit:
     def run(self):
         import time
         ctx, plan = self.ctx, self.plan
-        t = {"phase_a_issue": 0.0, "wait": 0.0, "import": 0.0, "run": 0.0, "send": 0.0}
+        t = {"phase_a_issue": 0.0, "wait": 0.0, "import": 0.0, "run": 0.0, "send": 0.0, "finish": 0.0}
         t0 = time.perf_counter()
         ctx.clear_imported_masks()
         if self.precompute:
@@ -226,7 +226,13 @@ class SequenceSplit:
             t["import"] += time.perf_counter() - t1
             self.bytes_received += n
         t0 = time.perf_counter()
-        ctx.run()
+        # a rank with successors hands its masks on as soon as the frame loop has finished; the voxel filter of its last
+        # keyframe groups (stream B) runs on under the sends and is collected by finish()
+        split = bool(plan.sends) and hasattr(ctx, "run_chain")
+        if split:
+            ctx.run_chain()
+        else:
+            ctx.run()
         t1 = time.perf_counter()
         t["run"] = t1 - t0
         for r, frames in plan.sends.items():
@@ -244,7 +250,11 @@ class SequenceSplit:
             else:
                 dist.send(buf, dst=r, group=self.group)
             self.bytes_sent += n
-        t["send"] = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        t["send"] = t2 - t1
+        if split:
+            ctx.finish()
+        t["finish"] = time.perf_counter() - t2
         self.timing = {k: v * 1e3 for k, v in t.items()}
 
 

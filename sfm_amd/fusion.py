@@ -41,7 +41,7 @@ EXPORTS = [
     "sfm_fusion_partition_counts_noalloc", "sfm_fusion_set_active_range", "sfm_fusion_import_masks",
     "sfm_fusion_clear_imported_masks", "sfm_fusion_export_masks", "sfm_fusion_precompute",
     "sfm_fusion_add_keyframe_se3", "sfm_fusion_se3_exp", "sfm_fusion_get_key_range", "sfm_fusion_set_key_range",
-    "sfm_fusion_get_cloud_index_range",
+    "sfm_fusion_get_cloud_index_range", "sfm_fusion_run_chain", "sfm_fusion_finish",
 ]
 SFM_RECORD_BYTES = 48
 
@@ -105,6 +105,8 @@ def load_library():
     L.sfm_fusion_set_neighbors.argtypes = [vp, u32, C.POINTER(u32), u32]
     L.sfm_fusion_set_covisibility.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), u64, u32, u32]
     L.sfm_fusion_run.argtypes = [vp]
+    L.sfm_fusion_run_chain.argtypes = [vp]
+    L.sfm_fusion_finish.argtypes = [vp]
     L.sfm_fusion_num_points.argtypes = [vp, C.POINTER(u64)]
     L.sfm_fusion_read_points.argtypes = [vp, vp, vp, vp, vp]
     L.sfm_fusion_get_stats.argtypes = [vp, C.POINTER(FusionStats)]
@@ -318,6 +320,14 @@ class FusionContext:
 
     def run(self):
         self._check(self._L.sfm_fusion_run(self._h))
+
+    def run_chain(self):
+        """First half of run(): returns when the frame loop has finished.  The masks may be exported from here on;
+        the voxel filter of the last keyframe groups still runs.  finish() completes the run."""
+        self._check(self._L.sfm_fusion_run_chain(self._h))
+
+    def finish(self):
+        self._check(self._L.sfm_fusion_finish(self._h))
 
     def num_points(self) -> int:
         n = C.c_uint64()

@@ -35,7 +35,11 @@ def _run_split(frames, gp, world, W=None, H=None, cost=dist_fusion.PIPELINE_COST
                 nb = sum(px[plan.frames[i]] for i in range(first, first + count))
                 ctx.import_masks(first, count, buf.data_ptr() + off, nb)
                 off += nb
-        ctx.run()
+        # a rank with successors hands its masks on between the two halves of its run, as SequenceSplit does
+        if plan.sends:
+            ctx.run_chain()
+        else:
+            ctx.run()
         for t, fr in plan.sends.items():
             buf = torch.empty(max(1, sum(px[g] for g in fr)), dtype=torch.uint8, device="cuda")
             off = 0
@@ -44,6 +48,8 @@ def _run_split(frames, gp, world, W=None, H=None, cost=dist_fusion.PIPELINE_COST
                 ctx.export_masks(first, count, buf.data_ptr() + off, nb)
                 off += nb
             mail[(r, t)] = buf
+        if plan.sends:
+            ctx.finish()
         ctxs.append(ctx)
     return plans, ctxs
 
@@ -158,4 +164,82 @@ def test_active_range_and_mask_calls_check_their_arguments():
     ctx.set_active_range(2, 2)
     ctx.run()
     assert ctx.num_points() == 0 and ctx.stats()["n_px"] == 0
+    ctx.close()
+
+
+def _all_masks(ctx, n, px):
+    import torch
+    buf = torch.empty(n * px, dtype=torch.uint8, device="cuda")
+    ctx.export_masks(0, n, buf.data_ptr(), n * px)
+    return buf.cpu().numpy()
+
+
+def test_a_run_in_two_halves():
+    """sfm_fusion_run_chain + sfm_fusion_finish: the masks are final (and may be exported) after the first half, the
+    second half completes the run as sfm_fusion_run would have -- here including a retry (the first guess of the
+    output capacity, one slot per 16 pixels, is too small for a cloud with nearly one voxel per accepted pixel)."""
+    W, H = 96, 72
+    seq = synth.make_sequence(12, W, H, K=(78.75, 78.75, 47.5, 35.5), window=3, yaw_step_deg=2.0)
+    frames = seq.frame_dicts()
+    op, gp = both_params(voxel_size=0.5, T_dist=500.0)
+    want = oracle.fuse(frames, op)
+    assert want.key.shape[0] > max(len(frames) * W * H // 16, 4096)     # the first attempt cannot hold the cloud
+    ctx = fusion.FusionContext(gp)
+    with pytest.raises(fusion.FusionError):
+        ctx.finish()                                                     # nothing in flight
+    for f in frames:
+        ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+    for i, f in enumerate(frames):
+        ctx.set_neighbors(i, f["nbrs"])
+    ctx.run_chain()
+    early = _all_masks(ctx, len(frames), W * H)
+    for call in (lambda: ctx.set_neighbors(0, []), lambda: ctx.set_active_range(0, 3), ctx.clear_imported_masks,
+                 ctx.precompute, ctx.run_chain, ctx.num_points, ctx.read_points, lambda: ctx.partition_counts(2),
+                 lambda: ctx.add_keyframe(frames[0]["depth"], frames[0]["bgr"], frames[0]["K"], frames[0]["T_wk"], frames[0]["T_kw"])):
+        with pytest.raises(fusion.FusionError):
+            call()                                                       # refused while the run is in flight
+    ctx.finish()
+    late = _all_masks(ctx, len(frames), W * H)
+    assert np.array_equal(early, late) and early.any()
+    xyz, bgr, key, tag = ctx.read_points()
+    assert np.array_equal(key, want.key) and np.array_equal(tag, want.tag) and np.array_equal(bgr, want.bgr)
+    assert np.array_equal(xyz.view(np.uint64), want.xyz.view(np.uint64))
+    fb, fa = ctx.frame_counts()
+    assert np.array_equal(fb, want.frame_before) and np.array_equal(fa, want.frame_after)
+    st = ctx.stats()
+    for k in ("n_px", "n_gather", "n_acc", "n_hit", "n_vox"):
+        assert st[k] == want.counters[k], k
+    # the second run fits at once; sfm_fusion_run after run_chain is the same as finish
+    ctx.run_chain()
+    ctx.run()
+    assert np.array_equal(ctx.read_points()[2], want.key)
+    with pytest.raises(fusion.FusionError):
+        ctx.finish()
+    ctx.close()
+
+
+def test_a_chain_that_cannot_hold_its_barrier_falls_back_inside_the_first_half(fusion_path, monkeypatch):
+    """With a barrier time limit of one tick the persistent chain gives up at once: sfm_fusion_run_chain itself must
+    rerun on the path without a device-wide barrier before it reports the masks final."""
+    if fusion_path == "pair":
+        pytest.skip("the kernel pair has no device-wide barrier")
+    monkeypatch.setenv("SFM_CHAIN_TIMEOUT_TICKS", "1")
+    W, H = 64, 48
+    seq = synth.make_sequence(8, W, H, K=(131.25, 131.25, 31.5, 23.5), window=2)
+    frames = seq.frame_dicts()
+    op, gp = both_params(voxel_size=30.0, T_dist=500.0)
+    want = oracle.fuse(frames, op)
+    ctx = fusion.FusionContext(gp)
+    for f in frames:
+        ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+    for i, f in enumerate(frames):
+        ctx.set_neighbors(i, f["nbrs"])
+    ctx.run_chain()
+    early = _all_masks(ctx, len(frames), W * H)
+    ctx.finish()
+    assert np.array_equal(early, _all_masks(ctx, len(frames), W * H))
+    xyz, bgr, key, tag = ctx.read_points()
+    assert np.array_equal(key, want.key) and np.array_equal(tag, want.tag)
+    assert np.array_equal(xyz.view(np.uint64), want.xyz.view(np.uint64))
+    assert ctx.stats()["chain_fallbacks"] == 1 and ctx.stats()["fused_chain"] == 0
     ctx.close()
