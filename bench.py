@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--two-phase", action="store_true",
                     help="one GPU: run every step as verdict_kernel (phase A) + accept_chain_kernel (phase B), the path "
                          "the waiting ranks of a sequence split take; measures the two terms of the scaling model")
+    ap.add_argument("--split-run", action="store_true",
+                    help="one GPU: run every step as sfm_fusion_run_chain + sfm_fusion_finish (what a rank with successors "
+                         "does: the voxel filter runs behind the chain, not under it) and report when the masks were final")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=500)
     args = ap.parse_args()
@@ -155,13 +158,22 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
     if world > 1:
         split = dist_fusion.SequenceSplit(ctx, plan, lambda g: W * H, rank, world, dev)
 
+    half = [0.0, 0.0]   # --split-run: host time until the masks were final, and until the run was complete
+
     def step():
         if split is not None:
             split.run()       # (phase A while waiting,) masks in from the earlier blocks, this block's chain, masks out
         else:
             if args.two_phase:
                 ctx.precompute()
-            ctx.run()
+            if args.split_run:
+                ts = time.perf_counter()
+                ctx.run_chain()
+                half[0] += time.perf_counter() - ts
+                ctx.finish()
+                half[1] += time.perf_counter() - ts
+            else:
+                ctx.run()
         if merger is not None:
             merger.exchange_and_reduce()
 
@@ -173,8 +185,10 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
     for _ in range(args.warmup):
         step()
     barrier()
+    half[0] = half[1] = 0.0
     # per-rank breakdown of the timed steps (host clocks; N > 1): what the scaling model of DESIGN.md section 6 is made of
-    acc = {"phase_a_ms": 0.0, "wait_ms": 0.0, "phase_b_ms": 0.0, "chain_host_ms": 0.0, "mask_send_ms": 0.0, "exchange_ms": 0.0}
+    acc = {"phase_a_ms": 0.0, "wait_ms": 0.0, "phase_b_ms": 0.0, "run_ms": 0.0, "chain_host_ms": 0.0, "mask_send_ms": 0.0,
+           "finish_ms": 0.0, "exchange_ms": 0.0}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if split is None:
@@ -186,7 +200,9 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
         acc["exchange_ms"] += (time.perf_counter() - tx) * 1e3
         sst = ctx.stats()
         acc["phase_a_ms"] += sst["precompute_ms"]          # device time of this rank's verdicts (0 on rank 0: fused chain)
-        acc["phase_b_ms"] += sst["last_run_ms"]            # device time of this rank's chain (fused on rank 0, accept on the others)
+        acc["phase_b_ms"] += sst["frame_kernels_ms"]       # device time of this rank's chain (fused on rank 0, accept on the others)
+        acc["run_ms"] += sst["last_run_ms"]                # ... and of the whole run: chain, then the voxel filter behind it
+        acc["finish_ms"] += split.timing["finish"]         # host: from the last mask sent to the run complete
         acc["wait_ms"] += split.timing["wait"]             # blocked in recv for the predecessors' masks (phase A runs under it)
         acc["chain_host_ms"] += split.timing["run"]
         acc["mask_send_ms"] += split.timing["send"]
@@ -224,11 +240,12 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
     kernel_bytes = observe_bytes(pst) + (scan_bytes(pst) if chain else 0)
     if pst["precomputed"]:
         # --two-phase (and ranks > 0 of a split sequence): the timed chain is accept_chain_kernel, which reads every
-        # pixel's verdict word and its first four stored hit pixels (4 + 16 B, dense), the mask byte of the pixels that
-        # reach geometric_check (<= 1 B per pixel), the 32-byte fused point of an accepted pixel, and writes its
-        # 40-byte list record and one mask byte per kept observation in a later keyframe (<= N_hit)
+        # pixel's verdict word and its first four stored hit pixels (4 + 16 B, dense), the mask byte of every pixel
+        # (1 B), the 8-byte voxel key of an accepted pixel, and writes its 16-byte list entry (tag + key: the fused
+        # point stays in the verdict record, finalize_kernel reads the winners' there) and one mask byte per kept
+        # observation in a later keyframe (<= N_hit)
         kernel_name = "accept_chain_kernel"
-        kernel_bytes = 21 * pst["n_px"] + 72 * pst["n_acc"] + pst["n_hit"]
+        kernel_bytes = 21 * pst["n_px"] + 24 * pst["n_acc"] + pst["n_hit"]
     bytes_per_launch = kernel_bytes / launches
     scan_avg_s = pst["scan_kernel_sum_ms"] * 1e-3 / launches
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
@@ -334,6 +351,10 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
         out["two_phase"] = {"phase_a_ms": st["precompute_ms"], "phase_b_ms": st["frame_kernels_ms"],
                             "note": "phase A = mask-independent verdicts of every pixel (divides by the number of GPUs); "
                                     "phase B = the ordered accept/mark/emit chain (does not)"}
+    if args.split_run and split is None:
+        out["split_run"] = {"masks_final_host_ms": half[0] / args.steps * 1e3, "run_complete_host_ms": half[1] / args.steps * 1e3,
+                            "chain_device_ms": st["frame_kernels_ms"],
+                            "note": "sfm_fusion_run_chain + sfm_fusion_finish: the voxel filter runs behind the chain"}
     if split is not None:
         out["mask_handover_bytes_rank0"] = split.bytes_sent // max(1, args.steps + args.warmup)
         mine = {k: v / args.steps for k, v in acc.items()}

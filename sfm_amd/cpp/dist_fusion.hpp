@@ -36,20 +36,53 @@ struct RankPlan {
 // Relative cost of a keyframe (per pixel) as rank 0's fused chain, as a later rank's phase A (verdicts) and as its
 // phase B (accept chain), measured on one MI355X.  Only the ratios matter, and only for speed.
 struct SplitCost {
-    double fused = 38.2, verdict = 42.3, accept = 12.8;
+    // microseconds per C3 keyframe on one MI355X: fused chain, phase A, phase B -- both chains as
+    // sfm_fusion_run_chain runs them, the voxel filter behind the chain -- and that voxel filter alone on the device
+    double fused = 34.3, verdict = 41.3, accept = 9.0, filter = 10.0;
     bool equal_blocks = false;
 };
 
+// The pipeline model behind block_shares: rank 0 chains from time 0, rank r > 0 computes its verdicts from time 0 and
+// chains when they are done and its predecessor has stopped chaining; a rank's voxel filter runs behind its own chain.
+inline double modelled_makespan(const std::vector<double> &shares, const SplitCost &c, double units = 1.0)
+{
+    double end = 0, worst = 0;
+    for (std::size_t r = 0; r < shares.size(); r++) {
+        const double n = shares[r] * units;
+        const double start = r == 0 ? end : std::max(end, c.verdict * n);
+        end = start + (r == 0 ? c.fused : c.accept) * n;
+        worst = std::max(worst, end + c.filter * n);
+    }
+    return worst;
+}
+
 // Share of the sequence each rank's block gets: every rank's phase A ends just when its predecessor's chain does
-// (rank 1's block is fused/verdict of rank 0's, every later one (1 + accept/verdict) times the one before).
+// (rank 1's block is fused/verdict of rank 0's, every later one (1 + accept/verdict) times the one before).  The voxel
+// filter behind a rank's chain is hidden under its successors' chains on every rank but the last: the last block is
+// shortened (the others keep their ratios) as far as the model gains from it.
 inline std::vector<double> block_shares(int world, const SplitCost &c = SplitCost{})
 {
     std::vector<double> s((std::size_t)world, 1.0);
     if (!c.equal_blocks)
         for (int r = 1; r < world; r++) s[r] = r == 1 ? c.fused / c.verdict : s[r - 1] * (1.0 + c.accept / c.verdict);
-    double total = 0;
-    for (double v : s) total += v;
-    for (double &v : s) v /= total;
+    auto normalise = [](std::vector<double> &v) {
+        double total = 0;
+        for (double x : v) total += x;
+        for (double &x : v) x /= total;
+    };
+    normalise(s);
+    if (!c.equal_blocks && c.filter > 0 && world > 1) {
+        std::vector<double> best = s;
+        double best_t = modelled_makespan(s, c);
+        for (int k = 1; k < 40; k++) {
+            std::vector<double> cand = s;
+            cand.back() *= 1.0 - k / 40.0;
+            normalise(cand);
+            const double t = modelled_makespan(cand, c);
+            if (t < best_t) { best = cand; best_t = t; }
+        }
+        s = best;
+    }
     return s;
 }
 

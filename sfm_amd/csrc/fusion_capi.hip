@@ -168,6 +168,7 @@ struct sfm_fusion_ctx {
     // the kernel is off the keyframe chain, and a chip-filling grid slows the chain kernels it
     // overlaps by more than it gains (r01v6 sweep: 64 -> 14.7 ms, 16 -> 13.2 ms, 4 -> 13.9 ms per C2 run)
     uint32_t table_wgs = 16;
+    uint32_t table_wgs_alone = 32;   // ... and behind the chain (sfm_fusion_run_chain; SFM_TABLE_WGS_ALONE overrides)
     uint32_t table_threads = 256;    // threads per table_group_kernel workgroup (SFM_TABLE_THREADS: 64, 128 or 256)
     uint32_t waves_per_cu = 28;      // resident observe waves per CU (SFM_FUSE_RESIDENT overrides)
     bool profile = false;         // per-launch start/stop events on the frame kernels
@@ -583,9 +584,13 @@ static inline bool div_trust()
 // One attempt with fixed capacities, first half: every launch of the attempt, the keyframe chain on stream A and the
 // table kernels on stream B.  Nothing here waits for the device.  table_cap is a power of two.  *refused: the runtime
 // would not take the cooperative grid (both streams are idle again; the caller reruns with the kernel pair).
-int run_launch(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t out_cap, bool *refused)
+// defer_tables (sfm_fusion_run_chain: somebody waits for this run's masks): the voxel filter does not run under the
+// chain, which it slows by 12 % (fused) to 27 % (accept chain), but behind it -- under the successor's chain, on a
+// device that has nothing else to do then, and with a grid sized for a device of its own (table_wgs_alone).
+int run_launch(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64_t out_cap, bool defer_tables, bool *refused)
 {
     *refused = false;
+    const uint32_t table_wgs = defer_tables ? c->table_wgs_alone : c->table_wgs;
     const size_t n = c->frames.size();
     const uint64_t list_cap = shard_cap * kListShards;
     if (shard_cap > 0xFFF00000ull)  // table_group_kernel walks a shard with 32-bit offsets (and a grid-sized stride)
@@ -597,8 +602,8 @@ int run_launch(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64
     // (with phase A's verdicts the fused points stay in the verdict records: finalize_kernel reads the winners there)
     if (!c->have_verdicts && (rc = ensure(c, c->d_list_xyz, 3 * list_cap))) return rc;
     // + the unused chunk tails of table_group_kernel's waves: at most two chunks per wave and launch
-    if ((rc = ensure(c, c->d_cand, list_cap + (uint64_t)((c->frames.size() + kGroup - 1) / kGroup) * c->table_wgs *
-                                                  kListShards * 4 * 2 * kCandChunk))) return rc;
+    if ((rc = ensure(c, c->d_cand, list_cap + (uint64_t)((c->frames.size() + kGroup - 1) / kGroup) *
+                                                  std::max(c->table_wgs, c->table_wgs_alone) * kListShards * 4 * 2 * kCandChunk))) return rc;
     if ((rc = ensure(c, c->d_out_key, out_cap))) return rc;
     if ((rc = ensure(c, c->d_out_tag, out_cap))) return rc;
     if ((rc = ensure(c, c->d_out_xyz, 3 * out_cap))) return rc;
@@ -692,6 +697,24 @@ int run_launch(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64
     if (use_verdicts) use_chain = c->chain && c->chain_items > 0;
     c->chain_ran = use_chain;
     c->verdicts_ran = use_verdicts;
+    // the voxel filter of one group of keyframes, on stream B
+    auto launch_tables = [&](size_t g, size_t g0, size_t g1) -> int {
+        t.f0 = (uint32_t)g0;
+        t.f1 = (uint32_t)g1;
+        t.group = (uint32_t)g;
+        // diagnostic only (wrong or no cloud): 1 = chain without its co-runner, 2 / 3 = half / an eighth of the
+        // shards, 4 = finalize_kernel only
+        const char *diag = std::getenv("SFM_DIAG_SKIP_TABLE");
+        if (diag && diag[0] == '1') return SFM_OK;
+        const uint32_t shards = !diag ? kListShards : diag[0] == '2' ? kListShards / 2 : diag[0] == '3' ? kListShards / 8 : 0;
+        if (shards) hipLaunchKernelGGL(table_group_kernel, dim3(table_wgs, shards), dim3(c->table_threads), 0, sb, t);
+        // the group's winners are final now (later groups hold later keyframes): gather them
+        HIP_TRY(c, hipMemcpyAsync(c->d_cand_end.p + g, &dev_ctr(c)->cand_count, sizeof(unsigned long long),
+                                  hipMemcpyDeviceToDevice, sb));
+        fa.group = (uint32_t)g;
+        hipLaunchKernelGGL(finalize_kernel, dim3(table_wgs * kListShards), dim3(256), 0, sb, fa);
+        return SFM_OK;
+    };
     for (size_t g = 0; g < n_groups; g++) {
         const size_t g0 = a0 + g * kGroup, g1 = std::min(a1, g0 + kGroup);
         bool group_event_recorded = false;
@@ -827,29 +850,22 @@ int run_launch(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64
                 hipLaunchKernelGGL(observe_frame_kernel, dim3(wgs), dim3(nw * kWave), lds, sa, nbp, a);
             }
         }
-        {
-            // list boundaries of the group: fuse_chain_kernel's last workgroup has written them; the kernel
-            // pair needs a snapshot of the append cursors, in stream order
-            if (!use_chain)
-                HIP_TRY(c, hipMemcpyAsync(c->d_group_end.p + g * kListShards * 8, dev_cursor(c),
-                                          kListShards * 8 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, sa));
-            if (!group_event_recorded) HIP_TRY(c, hipEventRecord(c->gev[g], sa));
+        // list boundaries of the group: fuse_chain_kernel's last workgroup has written them; the kernel
+        // pair needs a snapshot of the append cursors, in stream order
+        if (!use_chain)
+            HIP_TRY(c, hipMemcpyAsync(c->d_group_end.p + g * kListShards * 8, dev_cursor(c),
+                                      kListShards * 8 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, sa));
+        if (!group_event_recorded) HIP_TRY(c, hipEventRecord(c->gev[g], sa));
+        if (!defer_tables) {
             HIP_TRY(c, hipStreamWaitEvent(sb, c->gev[g], 0));
-            t.f0 = (uint32_t)g0;
-            t.f1 = (uint32_t)g1;
-            t.group = (uint32_t)g;
-            // diagnostic only (wrong or no cloud): 1 = chain without its co-runner, 2 / 3 = half / an eighth of the
-            // shards, 4 = finalize_kernel only
-            const char *diag = std::getenv("SFM_DIAG_SKIP_TABLE");
-            if (!diag || diag[0] != '1') {
-                const uint32_t shards = !diag ? kListShards : diag[0] == '2' ? kListShards / 2 : diag[0] == '3' ? kListShards / 8 : 0;
-                if (shards) hipLaunchKernelGGL(table_group_kernel, dim3(c->table_wgs, shards), dim3(c->table_threads), 0, sb, t);
-                // the group's winners are final now (later groups hold later keyframes): gather them
-                HIP_TRY(c, hipMemcpyAsync(c->d_cand_end.p + g, &dev_ctr(c)->cand_count, sizeof(unsigned long long),
-                                          hipMemcpyDeviceToDevice, sb));
-                fa.group = (uint32_t)g;
-                hipLaunchKernelGGL(finalize_kernel, dim3(c->table_wgs * kListShards), dim3(256), 0, sb, fa);
-            }
+            if ((rc = launch_tables(g, g0, g1))) return rc;
+        }
+    }
+    if (defer_tables && n_groups) {
+        HIP_TRY(c, hipStreamWaitEvent(sb, c->gev[n_groups - 1], 0));
+        for (size_t g = 0; g < n_groups; g++) {
+            const size_t g0 = a0 + g * kGroup, g1 = std::min(a1, g0 + kGroup);
+            if ((rc = launch_tables(g, g0, g1))) return rc;
         }
     }
     HIP_TRY(c, hipGetLastError());
@@ -1009,6 +1025,10 @@ int sfm_fusion_create(const sfm_fusion_params *params, int device, void *stream,
     if (const char *e = std::getenv("SFM_TABLE_WGS")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 1024) c->table_wgs = (uint32_t)v;
+    }
+    if (const char *e = std::getenv("SFM_TABLE_WGS_ALONE")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 1024) c->table_wgs_alone = (uint32_t)v;
     }
     if (ok && stream) {
         c->stream = (hipStream_t)stream;
@@ -1339,7 +1359,7 @@ int run_driver(sfm_fusion_ctx *c, bool stop_after_chain)
         uint32_t err = 0;
         if (!rs.launched) {
             bool refused = false;
-            if ((rc = run_launch(c, table_cap, shard_cap, out_cap, &refused))) return rc;
+            if ((rc = run_launch(c, table_cap, shard_cap, out_cap, stop_after_chain, &refused))) return rc;
             if (refused) {
                 err = kErrBarrier;
             } else {

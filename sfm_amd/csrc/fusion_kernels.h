@@ -39,6 +39,10 @@
 // the chain beside it is its traffic per microsecond, which goes up.
 #define SFM_TABLE_MARK_CAS 1
 #endif
+// table_group_kernel: an entry that repeats its left neighbour's voxel (same keyframe, larger tag) skips the table
+#ifndef SFM_TABLE_DEDUP
+#define SFM_TABLE_DEDUP 1
+#endif
 #ifndef SFM_DIAG_ACC_NOREC
 #define SFM_DIAG_ACC_NOREC 0    // diagnostic only (wrong cloud): accept_chain_kernel writes tags without reading or writing the voxel keys
 #endif
@@ -2046,9 +2050,18 @@ __global__ __launch_bounds__(256) void table_group_kernel(TableArgs a)
         const unsigned long long key = keyp[rc];   // unwritten (but readable) where the tag is empty
         const unsigned long long tag = r < n ? tag_ld : kEmpty;
         bool lower = false;
-        if (tag != kEmpty) {
+#if SFM_TABLE_DEDUP
+        // Neighbouring list entries are neighbouring accepted pixels of one 64-pixel run, and a 1-cm voxel holds several
+        // of them: an entry whose left neighbour in the wave is the same voxel of the same keyframe with a smaller tag
+        // can neither win the voxel nor be the keyframe's first entry of it.  It counts as "before" and is done.
+        const unsigned long long ptag = __shfl_up(tag, 1), pkey = __shfl_up(key, 1);
+        const bool dup = lane != 0u && ptag < tag && pkey == key && (uint32_t)(ptag >> 32) == (uint32_t)(tag >> 32);
+#else
+        const bool dup = false;
+#endif
+        if (tag != kEmpty) atomicAdd(&s_before[(uint32_t)(tag >> 32) - a.f0], 1u);
+        if (tag != kEmpty && !dup) {
             const uint32_t fr = (uint32_t)(tag >> 32) - a.f0;
-            atomicAdd(&s_before[fr], 1u);
             uint64_t h = mix64(key) & a.table_mask;
             unsigned probes = 0;
             bool found = false;

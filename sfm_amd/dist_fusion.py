@@ -62,10 +62,28 @@ def shard_components(nbrs: Sequence[Sequence[int]], weights: Sequence[int], worl
     return [sorted(x) for x in out]
 
 
-# Relative cost of a keyframe (per pixel) in the three roles a block can play, measured on one MI355X on the C3
-# workload: fused chain on rank 0, phase A (mask-independent verdicts) and phase B (accept
-# chain) on the later ranks.  Only the ratios matter, and only for speed: any split is exact.
-PIPELINE_COST = (38.2, 42.3, 12.8)
+# Cost of a keyframe in microseconds in the roles a block can play, measured on one MI355X on the C3 workload
+# (DESIGN.md section 6): fused chain on rank 0, phase A (mask-independent verdicts) and phase B (accept chain) on the
+# later ranks -- both chains as sfm_fusion_run_chain runs them, the voxel filter behind the chain and not under it --
+# and that voxel filter (table + finalize kernels alone on the device).  Only the ratios matter, and only for speed:
+# any split is exact.
+PIPELINE_COST = (34.3, 41.3, 9.0, 10.0)
+
+
+def modelled_makespan(shares, cost=PIPELINE_COST, units: float = 1.0) -> float:
+    """The pipeline model behind block_shares: rank 0 chains its block from time 0 (f per unit), rank r > 0 computes
+    its verdicts from time 0 (a per unit) and chains (b per unit) when they are done AND its predecessor has stopped
+    chaining; a rank's voxel filter (t per unit, the optional fourth cost) runs behind its own chain.  Returns the time
+    the last rank is done, for a sequence of `units` keyframes."""
+    f, a, b = cost[:3]
+    t = cost[3] if len(cost) > 3 else 0.0
+    end = worst = 0.0
+    for r, s in enumerate(shares):
+        n = s * units
+        start = end if r == 0 else max(end, a * n)
+        end = start + (f if r == 0 else b) * n
+        worst = max(worst, end + t * n)
+    return worst
 
 
 def block_shares(world: int, cost=PIPELINE_COST) -> list:
@@ -74,13 +92,26 @@ def block_shares(world: int, cost=PIPELINE_COST) -> list:
     kernel (f per unit) while rank 1 computes verdicts (a per unit) -- so block 1 is f/a of block 0 --, and each
     later rank has had (1 + b/a) times longer than the one before it (b per unit = the accept chain), so the blocks
     grow geometrically.  With equal blocks the later ranks idle after their phase A and rank 0's slow fused block
-    is as long as everyone's; with these shares the makespan is f*n0*(1 + b/a)^(N-1) instead of (f + (N-1)*b)*n/N."""
+    is as long as everyone's; with these shares the chain ends at f*n0*(1 + b/a)^(N-1) instead of (f + (N-1)*b)*n/N.
+    A fourth cost, the voxel filter behind a rank's chain, is hidden under the successors' chains on every rank but
+    the last: the last block is shortened (the others keep their ratios) as far as modelled_makespan gains from it."""
     if cost is None or world == 1:
         return [1.0 / world] * world
-    f, a, b = cost
+    f, a, b = cost[:3]
     shares = [1.0] + [f / a * (1.0 + b / a) ** (r - 1) for r in range(1, world)]
     total = sum(shares)
-    return [s / total for s in shares]
+    shares = [s / total for s in shares]
+    if len(cost) > 3 and cost[3] > 0.0:
+        best, best_t = shares, modelled_makespan(shares, cost)
+        for k in range(1, 40):   # the last block at 97.5 % ... 2.5 % of its just-in-time size
+            cand = shares[:-1] + [shares[-1] * (1.0 - k / 40.0)]
+            tot = sum(cand)
+            cand = [s / tot for s in cand]
+            t = modelled_makespan(cand, cost)
+            if t < best_t:
+                best, best_t = cand, t
+        shares = best
+    return shares
 
 
 def split_blocks(weights: Sequence[int], world: int, cost=None) -> list:

@@ -89,18 +89,19 @@ def test_plan_covers_every_keyframe_once_and_names_the_mask_traffic():
 def test_pipelined_block_shares():
     """Default block sizes: rank r's verdicts (phase A) are ready just when rank r-1 stops chaining, so the blocks
     grow along the ranks; the modelled makespan beats equal blocks, and any cost gives a valid cover."""
-    f, a, b = dist_fusion.PIPELINE_COST
+    f, a, b, tail = dist_fusion.PIPELINE_COST
 
     def makespan(blocks):
-        t = f * (blocks[0][1] - blocks[0][0])
-        for first, end in blocks[1:]:
-            t = max(t, a * (end - first)) + b * (end - first)
-        return t
+        return dist_fusion.modelled_makespan([(e - s) / 2000.0 for s, e in blocks], dist_fusion.PIPELINE_COST, 2000)
 
     for world in (2, 3, 4, 8):
         shares = dist_fusion.block_shares(world)
         assert abs(sum(shares) - 1.0) < 1e-12 and all(s > 0 for s in shares)
-        assert all(shares[r + 1] > shares[r] for r in range(1, world - 1))
+        assert all(shares[r + 1] > shares[r] for r in range(1, world - 2))
+        # the last rank's voxel filter is nobody's to hide: its block is at most the just-in-time size, shorter where
+        # the model gains from it (with these costs: from four ranks on)
+        jit = shares[-2] * (1.0 + b / a) if world > 2 else shares[0] * f / a
+        assert shares[-1] <= jit * (1 + 1e-12) and (world < 4 or shares[-1] < 0.9 * jit)
         blocks = dist_fusion.split_blocks([921600] * 2000, world, dist_fusion.PIPELINE_COST)
         assert blocks[0][0] == 0 and blocks[-1][1] == 2000
         assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
@@ -114,6 +115,9 @@ def test_pipelined_block_shares():
             t += b * (end - first)
     assert dist_fusion.block_shares(1) == [1.0]
     assert dist_fusion.block_shares(4, None) == [0.25] * 4
+    # three costs (no filter term): the plain geometric shares
+    sh = dist_fusion.block_shares(4, (10.0, 40.0, 30.0))
+    assert abs(sh[1] / sh[0] - 0.25) < 1e-12 and abs(sh[3] / sh[2] - 1.75) < 1e-12
     # more ranks than keyframes: empty blocks are allowed, the cover stays exact
     blocks = dist_fusion.split_blocks([1] * 3, 8, dist_fusion.PIPELINE_COST)
     assert blocks[0][0] == 0 and blocks[-1][1] == 3 and sum(e - s for s, e in blocks) == 3
