@@ -226,7 +226,11 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
     pst = st
     if rank == 0:
         ctx.set_profiling(True)
-        ctx.run()
+        if args.split_run and split is None:
+            ctx.run_chain()
+            ctx.finish()
+        else:
+            ctx.run()
         pst = ctx.stats()
         ctx.set_profiling(False)
     if world > 1:

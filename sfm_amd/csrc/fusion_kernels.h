@@ -40,6 +40,10 @@
 #define SFM_TABLE_MARK_CAS 1
 #endif
 // table_group_kernel: an entry that repeats its left neighbour's voxel (same keyframe, larger tag) skips the table
+// diagnostic (wrong cloud): accept_chain_kernel reads one stored hit per pixel instead of four -- what the bytes cost
+#ifndef SFM_DIAG_ACC_ONEHIT
+#define SFM_DIAG_ACC_ONEHIT 0
+#endif
 #ifndef SFM_TABLE_DEDUP
 #define SFM_TABLE_DEDUP 1
 #endif
@@ -1852,7 +1856,7 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                 const uint32_t pa = inv[j] ? pixv[j] : 0u;
                 infov[j] = mine ? (uint32_t)ldg(V.info + pa) : 0u;  // (uniform conditions: an empty keyframe has nothing to read)
 #pragma unroll
-                for (int q = 0; q < 4; q++) h[j][q] = (mine && nl) ? ldg(V.hits + (size_t)min((uint32_t)q, ql) * npx + pa) : kNoHit;
+                for (int q = 0; q < 4; q++) h[j][q] = (mine && nl) ? ldg(V.hits + (size_t)(SFM_DIAG_ACC_ONEHIT ? 0u : min((uint32_t)q, ql)) * npx + pa) : kNoHit;
             }
             __syncthreads();  // B1
             if (s_go == 0u) {
@@ -1868,7 +1872,7 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                         const uint32_t pa = inv[j] ? pixv[j] : 0u;
                         infov[j] = (uint32_t)ldg(V.info + pa);
 #pragma unroll
-                        for (int q = 0; q < 4; q++) h[j][q] = nl ? ldg(V.hits + (size_t)min((uint32_t)q, ql) * npx + pa) : kNoHit;
+                        for (int q = 0; q < 4; q++) h[j][q] = nl ? ldg(V.hits + (size_t)(SFM_DIAG_ACC_ONEHIT ? 0u : min((uint32_t)q, ql)) * npx + pa) : kNoHit;
                     }
                 }
                 // mask == 0 (:100): every lane with a pixel asks for its own byte, whatever its verdict -- all the loads
