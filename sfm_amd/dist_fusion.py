@@ -266,6 +266,7 @@ class SequenceSplit:
             ctx.run()
         t1 = time.perf_counter()
         t["run"] = t1 - t0
+        sent = []
         for r, frames in plan.sends.items():
             n = sum(self.px(g) for g in frames)
             buf = self._send_buf[r]
@@ -274,18 +275,22 @@ class SequenceSplit:
                 nb = sum(self.px(plan.frames[i]) for i in range(first, first + count))
                 ctx.export_masks(first, count, buf.data_ptr() + off, nb)
                 off += nb
+            # non-blocking: a successor that is not in its recv yet (it takes its predecessors in rank order) does not
+            # hold up the sends to the others, nor this rank's finish()
             if self._staged(buf):
                 h = self._host_buf[(id(self._send_buf), r)]
                 h.copy_(buf)
-                dist.send(h, dst=r, group=self.group)
+                sent.append(dist.isend(h, dst=r, group=self.group))
             else:
-                dist.send(buf, dst=r, group=self.group)
+                sent.append(dist.isend(buf, dst=r, group=self.group))
             self.bytes_sent += n
         t2 = time.perf_counter()
         t["send"] = t2 - t1
         if split:
             ctx.finish()
         t["finish"] = time.perf_counter() - t2
+        for w in sent:   # the send buffers are free again when run() returns
+            w.wait()
         self.timing = {k: v * 1e3 for k, v in t.items()}
 
 

@@ -60,7 +60,7 @@ def test_two_rank_rehearsal_line(fusion_path):
     pr = j["per_rank"]
     assert len(pr) == 2 and sum(r["keyframes"] for r in pr) == 24
     for r in pr:
-        for k in ("phase_a_ms", "wait_ms", "phase_b_ms", "exchange_ms", "mask_send_ms"):
+        for k in ("phase_a_ms", "wait_ms", "phase_b_ms", "run_ms", "chain_host_ms", "mask_send_ms", "finish_ms", "exchange_ms"):
             assert r[k] >= 0.0, (k, r)
     assert pr[0]["phase_a_ms"] == 0.0 and pr[1]["phase_a_ms"] > 0.0      # rank 0 runs the fused chain, rank 1 the two phases
     assert pr[0]["phase_b_ms"] > 0.0 and pr[1]["phase_b_ms"] > 0.0 and pr[1]["wait_ms"] > 0.0

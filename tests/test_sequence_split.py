@@ -40,6 +40,8 @@ class OracleBlockCtx(NumpyCtx):
         self.frames, self.active, self.gids = frames_local, active_local, global_ids
         self.seed = {}
         self.masks = None
+        self.in_flight = False
+        self.halves = 0
         self.cloud = None
 
     def clear_imported_masks(self):
@@ -57,6 +59,19 @@ class OracleBlockCtx(NumpyCtx):
     def run(self):
         p = oracle.default_params(**PARAMS)
         self.cloud, self.masks = oracle.fuse(self.frames, p, active=self.active, mask_seed=self.seed, want_masks=True)
+        NumpyCtx.__init__(self, self.cloud, self.gids)
+
+    # the run in two halves, as SequenceSplit drives a rank with successors: masks after the first, cloud after the second
+    def run_chain(self):
+        assert not self.in_flight
+        p = oracle.default_params(**PARAMS)
+        self.cloud, self.masks = oracle.fuse(self.frames, p, active=self.active, mask_seed=self.seed, want_masks=True)
+        self.in_flight = True
+        self.halves += 1
+
+    def finish(self):
+        assert self.in_flight
+        self.in_flight = False
         NumpyCtx.__init__(self, self.cloud, self.gids)
 
     def export_masks(self, first, count, ptr, nbytes):
@@ -165,6 +180,8 @@ def _worker(rank, world, port, out_dir, closure, n_kf=10):
     for _ in range(2):  # a second pass starts from clean imported masks again
         split.run()
         n = ex.exchange_and_reduce()
+    # a rank with successors ran in two halves (masks out in between), the others in one piece
+    assert ctx.halves == (2 if plan.sends else 0) and not ctx.in_flight
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), ctx.result)
     np.save(os.path.join(out_dir, f"traffic{rank}.npy"), np.array([split.bytes_sent, split.bytes_received]))
     t = torch.tensor([n], dtype=torch.int64)
