@@ -44,6 +44,13 @@
 #ifndef SFM_DIAG_ACC_ONEHIT
 #define SFM_DIAG_ACC_ONEHIT 0
 #endif
+// accept_chain_kernel: 1 = the accepted pixels' hit words packed through LDS, so that the marks leave as full 64-lane
+// instructions instead of sixteen quarter-full ones per wave.  Bit-exact; measured no gain on C3 (18.5 against 18.4 ms)
+// and slower on C2 (2.94 against 2.76 ms), profiles/r03_ab_accept_chain.txt exp23: what the marks' acknowledgement waits
+// for is the number of partial-line writes at the memory side, not the number of store instructions.  Off.
+#ifndef SFM_ACC_COMPACT_MARKS
+#define SFM_ACC_COMPACT_MARKS 0
+#endif
 #ifndef SFM_TABLE_DEDUP
 #define SFM_TABLE_DEDUP 1
 #endif
@@ -1776,6 +1783,9 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
     __shared__ unsigned int s_wave[kWave], s_off[kWave];
     __shared__ unsigned int s_go;
     __shared__ unsigned long long s_base;
+#if SFM_ACC_COMPACT_MARKS
+    __shared__ uint4 s_hits[kAccDataWaves * kAccIter * kWave];  // 60 KB: every data wave's rows for its packed hit words
+#endif
     const ChainArgs &a = aa.c;
     const unsigned lane = lane_id();
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1895,13 +1905,39 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                     pos[j] = lane_rank(m);
                     if (lane == 0) s_wave[j * kAccDataWaves + dw] = (unsigned)__popcll(m);
                 }
+                if (t0 == 0) chain_wave_stamp<STAMPS>(a, f, 16, w);  // diagnostic build: this wave's mask bytes are back
                 // the marks (:152-154) of the accepted pixels, into the masks of keyframes still to come: the first four
                 // later neighbours from the registers ...
+#if SFM_ACC_COMPACT_MARKS
+                // (measured variant, off: see the macro) the accepted pixels' hit words go through the wave's own LDS rows,
+                // packed, and leave as one round of four instructions per 64 accepted pixels instead of sixteen
+                // quarter-full ones.  (LDS operations of one wave execute in order; nobody else touches the rows.)
+                {
+                    unsigned tot = 0;
+                    uint4 *row = s_hits + dw * (kAccIter * kWave);
+#pragma unroll
+                    for (int j = 0; j < kAccIter; j++) {
+                        if (acc[j]) row[tot + pos[j]] = make_uint4(h[j][0], h[j][1], h[j][2], h[j][3]);
+                        tot += (unsigned)__popcll(__ballot(acc[j]));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (unsigned r0 = 0; r0 < tot; r0 += kWave) {  // wave-uniform
+                        const bool valid = r0 + lane < tot;
+                        const uint4 hv = row[valid ? r0 + lane : 0u];
+                        if (valid && 0u < nl && hv.x != kNoHit) mask_store_coherent(later_mask[0] + hv.x);
+                        if (valid && 1u < nl && hv.y != kNoHit) mask_store_coherent(later_mask[1] + hv.y);
+                        if (valid && 2u < nl && hv.z != kNoHit) mask_store_coherent(later_mask[2] + hv.z);
+                        if (valid && 3u < nl && hv.w != kNoHit) mask_store_coherent(later_mask[3] + hv.w);
+                    }
+                }
+#else
 #pragma unroll
                 for (int j = 0; j < kAccIter; j++)
 #pragma unroll
                     for (int q = 0; q < 4; q++)
                         if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit) mask_store_coherent(later_mask[q] + h[j][q]);
+#endif
                 // ... the others four at a time (unconditional loads: a lane without an accepted pixel reads element 0)
                 for (uint32_t s0 = 4; s0 < nl; s0 += 4) {
                     uint32_t h2[kAccIter][4];
@@ -1932,6 +1968,7 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 static_assert(kAccIter == 4, "the counted wait names kAccIter loads");
                 asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                if (t0 == 0) chain_wave_stamp<STAMPS>(a, f, 32, w);  // ... its marks are acknowledged
                 __syncthreads();  // B2
                 __syncthreads();  // B3
                 // the accepted pixels' list entries, behind the arrival

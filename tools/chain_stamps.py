@@ -32,7 +32,18 @@ for f in (1, 2, 8, 16, 30):
             print("   %-28s min %6.2f  p50 %6.2f  max %6.2f" % (n, col.min(), np.percentile(col, 50), col.max()))
 # per wave (fuse_chain_kernel only): when wave w left step B's first round, and when it was ready for the NEXT keyframe
 # (fusion and preparation done), relative to its workgroup's pass of the barrier (thread 0, slot 1)
-if s[:, :, 16:48].any():
+if s[:, :, 16:48].any() and "--two-phase" in extra:
+    # accept_chain_kernel: data waves 1..15, relative to the moment their workgroup passed the barrier
+    for f in (2, 8, 16):
+        ref = s[f][:, 1:2]
+        back = (s[f][:, 17:32] - ref) / 100.0
+        acked = (s[f][:, 33:48] - ref) / 100.0
+        print("keyframe +%d, data waves 1..15, median over workgroups (us after the workgroup passed the barrier):" % f)
+        print("   mask bytes back    " + " ".join("%5.2f" % np.median(back[:, w]) for w in range(15)))
+        print("   marks acknowledged " + " ".join("%5.2f" % np.median(acked[:, w]) for w in range(15)))
+        print("   slowest wave of a workgroup: masks back p50 %.2f max %.2f; marks acknowledged p50 %.2f max %.2f" % (
+            np.median(back.max(axis=1)), back.max(), np.median(acked.max(axis=1)), acked.max()))
+elif s[:, :, 16:48].any():
     for f in (2, 8, 16):
         ref = s[f][:, 1:2]
         bdone = (s[f][:, 32:48] - ref) / 100.0
