@@ -44,12 +44,16 @@
 #ifndef SFM_DIAG_ACC_ONEHIT
 #define SFM_DIAG_ACC_ONEHIT 0
 #endif
-// accept_chain_kernel: 1 = the accepted pixels' hit words packed through LDS, so that the marks leave as full 64-lane
-// instructions instead of sixteen quarter-full ones per wave.  Bit-exact; measured no gain on C3 (18.5 against 18.4 ms)
-// and slower on C2 (2.94 against 2.76 ms), profiles/r03_ab_accept_chain.txt exp23: what the marks' acknowledgement waits
-// for is the number of partial-line writes at the memory side, not the number of store instructions.  Off.
-#ifndef SFM_ACC_COMPACT_MARKS
-#define SFM_ACC_COMPACT_MARKS 0
+// (Measured and removed, profiles/r03_ab_accept_chain.txt exp23: the accepted pixels' hit words packed through LDS so that
+// the marks leave as full 64-lane instructions instead of sixteen quarter-full ones per wave -- bit-exact, no gain on C3,
+// slower on C2: what the marks' acknowledgement waits for is partial-line writes at the memory side, not instructions.)
+// accept_chain_kernel: 1 = only the marks into the next keyframe are waited for at the barrier, the marks into later
+// keyframes leave behind the arrival (they have one more barrier to go, and the next keyframe's counted wait covers
+// them).  Bit-exact; measured no gain on C3 (18.4 ms either way) and slower on C2 (2.94 against 2.75 ms),
+// profiles/r03_ab_accept_chain.txt exp24: a quarter of the marks is acknowledged no sooner than all of them, and the
+// other three quarters then stand in front of the next keyframe's mask loads.  Off.
+#ifndef SFM_ACC_DEFER_FAR_MARKS
+#define SFM_ACC_DEFER_FAR_MARKS 0
 #endif
 #ifndef SFM_TABLE_DEDUP
 #define SFM_TABLE_DEDUP 1
@@ -1783,9 +1787,6 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
     __shared__ unsigned int s_wave[kWave], s_off[kWave];
     __shared__ unsigned int s_go;
     __shared__ unsigned long long s_base;
-#if SFM_ACC_COMPACT_MARKS
-    __shared__ uint4 s_hits[kAccDataWaves * kAccIter * kWave];  // 60 KB: every data wave's rows for its packed hit words
-#endif
     const ChainArgs &a = aa.c;
     const unsigned lane = lane_id();
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1906,38 +1907,21 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                     if (lane == 0) s_wave[j * kAccDataWaves + dw] = (unsigned)__popcll(m);
                 }
                 if (t0 == 0) chain_wave_stamp<STAMPS>(a, f, 16, w);  // diagnostic build: this wave's mask bytes are back
-                // the marks (:152-154) of the accepted pixels, into the masks of keyframes still to come: the first four
-                // later neighbours from the registers ...
-#if SFM_ACC_COMPACT_MARKS
-                // (measured variant, off: see the macro) the accepted pixels' hit words go through the wave's own LDS rows,
-                // packed, and leave as one round of four instructions per 64 accepted pixels instead of sixteen
-                // quarter-full ones.  (LDS operations of one wave execute in order; nobody else touches the rows.)
-                {
-                    unsigned tot = 0;
-                    uint4 *row = s_hits + dw * (kAccIter * kWave);
-#pragma unroll
-                    for (int j = 0; j < kAccIter; j++) {
-                        if (acc[j]) row[tot + pos[j]] = make_uint4(h[j][0], h[j][1], h[j][2], h[j][3]);
-                        tot += (unsigned)__popcll(__ballot(acc[j]));
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    for (unsigned r0 = 0; r0 < tot; r0 += kWave) {  // wave-uniform
-                        const bool valid = r0 + lane < tot;
-                        const uint4 hv = row[valid ? r0 + lane : 0u];
-                        if (valid && 0u < nl && hv.x != kNoHit) mask_store_coherent(later_mask[0] + hv.x);
-                        if (valid && 1u < nl && hv.y != kNoHit) mask_store_coherent(later_mask[1] + hv.y);
-                        if (valid && 2u < nl && hv.z != kNoHit) mask_store_coherent(later_mask[2] + hv.z);
-                        if (valid && 3u < nl && hv.w != kNoHit) mask_store_coherent(later_mask[3] + hv.w);
-                    }
-                }
+                // The marks (:152-154) of the accepted pixels, into the masks of keyframes still to come.  (Only the marks
+                // into the NEXT keyframe have to be visible when the barrier opens: the later neighbours of keyframe f are
+                // ascending, so slot q is keyframe f+1+q or later and has q more barriers to go.  SFM_ACC_DEFER_FAR_MARKS
+                // sends slot 0 now and the others behind the arrival: measured, no gain, see the macro.)
+#if SFM_ACC_DEFER_FAR_MARKS
+                constexpr int kNearSlots = 1;
 #else
+                constexpr int kNearSlots = 4;
+#endif
 #pragma unroll
                 for (int j = 0; j < kAccIter; j++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
+                    for (int q = 0; q < kNearSlots; q++)
                         if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit) mask_store_coherent(later_mask[q] + h[j][q]);
-#endif
+#if !SFM_ACC_DEFER_FAR_MARKS
                 // ... the others four at a time (unconditional loads: a lane without an accepted pixel reads element 0)
                 for (uint32_t s0 = 4; s0 < nl; s0 += 4) {
                     uint32_t h2[kAccIter][4];
@@ -1953,6 +1937,7 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                             if (acc[j] && s0 + (uint32_t)q < nl && h2[j][q] != kNoHit)
                                 mask_store_coherent(later_mask[s0 + q] + h2[j][q]);
                 }
+#endif
                 // the accepted pixels' voxel keys (cold, scattered 8-byte reads of the verdict records; unconditional loads:
                 // their number is fixed), requested now so that their round trip runs under the marks' acknowledgement and
                 // the arrival ...  (the fused point itself stays where verdict_kernel left it: finalize_kernel reads it
@@ -1986,6 +1971,31 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                         }
                     }
                 }
+#if SFM_ACC_DEFER_FAR_MARKS
+                // ... and the marks into the keyframes after the next one go out here, behind the arrival: they are older
+                // than every memory operation this wave issues for keyframe f+1, so the counted wait of keyframe f+1 (all
+                // but its kAccIter youngest loads) covers them -- they are acknowledged before the barrier in front of
+                // keyframe f+2 opens, which is the first that may read them.  (The last keyframe of a launch: the kernel ends.)
+#pragma unroll
+                for (int j = 0; j < kAccIter; j++)
+#pragma unroll
+                    for (int q = kNearSlots; q < 4; q++)
+                        if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit) mask_store_coherent(later_mask[q] + h[j][q]);
+                for (uint32_t s0 = 4; s0 < nl; s0 += 4) {  // more than four later neighbours: four at a time
+                    uint32_t h2[kAccIter][4];
+#pragma unroll
+                    for (int j = 0; j < kAccIter; j++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            h2[j][q] = ldg(V.hits + (size_t)min(s0 + (uint32_t)q, nl - 1u) * npx + (acc[j] ? pixv[j] : 0u));
+#pragma unroll
+                    for (int j = 0; j < kAccIter; j++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (acc[j] && s0 + (uint32_t)q < nl && h2[j][q] != kNoHit)
+                                mask_store_coherent(later_mask[s0 + q] + h2[j][q]);
+                }
+#endif
                 // (s_wave is rewritten by the next pass's data waves, s_off and s_base by its scan: both behind syncs
                 // that every wave reaches only after it has read this pass's values)
                 if (mine == 0) break;
