@@ -7,6 +7,7 @@
 #include "dist_fusion.hpp"
 #include "replay.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -16,8 +17,41 @@
 
 int main(int argc, char **argv)
 {
+    if (argc == 6 && std::string(argv[1]) == "--plan") {
+        // dist_reconstruct --plan <keyframes> <window> <world> <closure>: the block plan of a synthetic sequence (keyframe i
+        // names i-window .. i+window; closure > 0: keyframe 2 also names keyframe `closure`), one line per rank -- no GPU,
+        // no RCCL.  tests/test_sequence_split.py compares it with the Python planner's.
+        const std::size_t n = (std::size_t)std::atoll(argv[2]);
+        const long window = std::atol(argv[3]), closure = std::atol(argv[5]);
+        const int world = std::atoi(argv[4]);
+        std::vector<std::vector<std::uint32_t>> nbrs(n);
+        for (std::size_t i = 0; i < n; i++)
+            for (long j = (long)i - window; j <= (long)i + window; j++)
+                if (j >= 0 && j < (long)n && j != (long)i) nbrs[i].push_back((std::uint32_t)j);
+        if (closure > 0 && n > 2 && closure < (long)n) {
+            nbrs[2].push_back((std::uint32_t)closure);
+            std::sort(nbrs[2].begin(), nbrs[2].end());
+            nbrs[2].erase(std::unique(nbrs[2].begin(), nbrs[2].end()), nbrs[2].end());
+        }
+        const auto plans = sfm_amd::plan_sequence(nbrs, std::vector<std::uint64_t>(n, 921600), world);
+        for (int r = 0; r < world; r++) {
+            const auto &p = plans[r];
+            std::cout << r << " block " << p.first << " " << p.end << " frames " << p.frames.size();
+            for (const auto &[t, fr] : p.sends) {
+                std::cout << " send " << t << ":";
+                for (auto g : fr) std::cout << g << ",";
+            }
+            for (const auto &[q, fr] : p.recvs) {
+                std::cout << " recv " << q << ":";
+                for (auto g : fr) std::cout << g << ",";
+            }
+            std::cout << "\n";
+        }
+        return 0;
+    }
     if (argc < 3) {
-        std::cerr << "usage: dist_reconstruct <dump> <out> [--voxel-size V] [--t-dist T]\n";
+        std::cerr << "usage: dist_reconstruct <dump> <out> [--voxel-size V] [--t-dist T]\n"
+                     "       dist_reconstruct --plan <keyframes> <window> <world> <closure>\n";
         return 2;
     }
     try {

@@ -269,3 +269,26 @@ def test_oracle_helper_is_consistent():
     assert_clouds_equal(a, b)
     # (the reference marks earlier neighbours too, :152-154; nobody reads those masks again)
     assert len(masks) == 6 and all(m.any() for m in masks)
+
+
+def test_the_cpp_planner_and_the_python_planner_cut_alike():
+    """sfm_amd/cpp/dist_fusion.hpp plan_sequence against dist_fusion.plan_sequence: same blocks, same mask traffic, for
+    several rank counts, with and without an edge that jumps blocks (every rank of a job computes the plan itself; the two
+    hosts must never disagree about it).  `dist_reconstruct --plan` touches neither the GPU nor RCCL."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "sfm_amd", "cpp", "dist_reconstruct")
+    assert os.path.exists(exe), "run ./build.sh"
+    for n, window, world, closure in [(41, 4, 4, 30), (2000, 4, 8, 0), (2000, 4, 16, 1500), (10, 2, 3, 0), (3, 1, 8, 0), (500, 4, 2, 0)]:
+        r = subprocess.run([exe, "--plan", str(n), str(window), str(world), str(closure)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        nbrs = [[j for j in range(i - window, i + window + 1) if 0 <= j < n and j != i] for i in range(n)]
+        if closure > 0 and n > 2 and closure < n:
+            nbrs[2] = sorted(set(nbrs[2] + [closure]))
+        want = []
+        for rank, p in enumerate(dist_fusion.plan_sequence(nbrs, [921600] * n, world)):
+            line = "%d block %d %d frames %d" % (rank, p.first, p.end, len(p.frames))
+            line += "".join(" send %d:%s," % (t, ",".join(map(str, f))) for t, f in p.sends.items())
+            line += "".join(" recv %d:%s," % (q, ",".join(map(str, f))) for q, f in p.recvs.items())
+            want.append(line)
+        assert r.stdout.splitlines() == want, (n, window, world, closure)
