@@ -224,7 +224,7 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
     # every dispatch of it on the library's stream
     # (rank 0 alone: the other ranks wait, so that nothing else touches a GPU that a rehearsal shares)
     pst = st
-    if rank == 0:
+    if rank == 0 and not os.environ.get("SFM_DIAG_ONE_LAUNCH"):   # (that diagnostic has no per-group launches to time)
         ctx.set_profiling(True)
         if args.split_run and split is None:
             ctx.run_chain()

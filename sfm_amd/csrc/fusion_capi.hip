@@ -715,6 +715,9 @@ int run_launch(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64
         hipLaunchKernelGGL(finalize_kernel, dim3(table_wgs * kListShards), dim3(256), 0, sb, fa);
         return SFM_OK;
     };
+    // diagnostic only (wrong cloud: the groups' list boundaries are not made): the whole chain as ONE launch, to price
+    // the dispatch gaps and launch ramps between the groups' launches (needs the filter behind the chain)
+    const bool diag_one_launch = defer_tables && std::getenv("SFM_DIAG_ONE_LAUNCH") != nullptr;
     for (size_t g = 0; g < n_groups; g++) {
         const size_t g0 = a0 + g * kGroup, g1 = std::min(a1, g0 + kGroup);
         bool group_event_recorded = false;
@@ -740,11 +743,13 @@ int run_launch(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64
                                    (const FrameDev *)c->d_frames.p, (const VerdictDev *)c->d_verdicts.p,
                                    (uint8_t *const *)c->d_later_masks.p, aa);
             }
+        } else if (use_chain && diag_one_launch && g > 0) {
+            // (diagnostic: the first launch took every keyframe)
         } else if (use_chain) {
             // :48-52 for keyframes [g0, g1) in one launch; order is kept by the in-kernel barrier
             ChainArgs ca;
             ca.f0 = (uint32_t)g0;
-            ca.f1 = (uint32_t)g1;
+            ca.f1 = (uint32_t)(diag_one_launch ? a1 : g1);
             ca.item_cap = c->chain_items;
             ca.group = (uint32_t)g;
             ca.list = list;
