@@ -116,3 +116,34 @@ def test_c2_full_workload_against_oracle(fusion_path):
     want = oracle.fuse(seq.frame_dicts(0, n), op, n_threads=16)
     assert want.key.shape[0] > 1500000
     assert_same_cloud(dict(xyz=xyz, bgr=bgr, key=key, tag=tag, stats=st, frame_before=fb, frame_after=fa), want)
+
+
+def test_c2_full_workload_in_four_blocks_equals_the_single_run(fusion_path):
+    """The same 500-keyframe workload cut into four blocks as a sequence split runs them -- rank 0 on the fused chain, the
+    others in two phases, every rank with successors through sfm_fusion_run_chain / export_masks / sfm_fusion_finish --
+    then the voxel exchange: the union is the single run's cloud bit for bit (which the test above pins to the oracle),
+    and the ranks' counters add up to the single run's."""
+    if fusion_path != "chain":
+        pytest.skip("full-size run once, on the default path")
+    import torch
+    from test_gpu_sequence_split import _exchange, _run_split
+    n = 500
+    seq = synth.make_sequence(n, 640, 480, K=(525.0, 525.0, 319.5, 239.5), device=torch.device("cuda", 0),
+                              seed=20240315, components=1, radius_m=0.8)
+    _, gp = both_params(voxel_size=10.0, T_dist=500.0)
+    ctx = _ctx_from_device_sequence(seq, gp, n)
+    ctx.run()
+    xyz, bgr, key, tag = ctx.read_points()
+    st = ctx.stats()
+    ctx.close()
+    frames = seq.frame_dicts(0, n)
+    plans, ctxs = _run_split(frames, gp, 4, two_phase_later=True)
+    assert [c.stats()["precomputed"] for c in ctxs] == [0, 1, 1, 1]
+    for k in ("n_px", "n_gather", "n_acc", "n_hit"):
+        assert sum(c.stats()[k] for c in ctxs) == st[k], k
+    xyz4, bgr4, key4, tag4 = _exchange(ctxs, 4)
+    for c in ctxs:
+        c.close()
+    assert key.shape[0] > 1500000
+    assert np.array_equal(key4, key) and np.array_equal(tag4, tag) and np.array_equal(bgr4, bgr)
+    assert np.array_equal(xyz4.view(np.uint64), xyz.view(np.uint64))

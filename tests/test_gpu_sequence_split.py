@@ -12,8 +12,9 @@ from helpers import both_params
 pytestmark = pytest.mark.gpu
 
 
-def _run_split(frames, gp, world, W=None, H=None, cost=dist_fusion.PIPELINE_COST):
-    """W, H None: every keyframe has its own size (the mask buffers are packed back to back)."""
+def _run_split(frames, gp, world, W=None, H=None, cost=dist_fusion.PIPELINE_COST, two_phase_later=False):
+    """W, H None: every keyframe has its own size (the mask buffers are packed back to back).  two_phase_later: ranks > 0
+    compute their verdicts first (sfm_fusion_precompute), as SequenceSplit has them do while they wait."""
     import torch
     nbrs = [f["nbrs"] for f in frames]
     px = [f["depth"].shape[0] * f["depth"].shape[1] for f in frames]
@@ -28,6 +29,8 @@ def _run_split(frames, gp, world, W=None, H=None, cost=dist_fusion.PIPELINE_COST
             ctx.set_neighbors(plan.local[g], [plan.local[j] for j in frames[g]["nbrs"]])
         ctx.set_global_order(plan.frames)
         ctx.set_active_range(*plan.active_local)
+        if two_phase_later and r > 0:
+            ctx.precompute()
         for q, fr in plan.recvs.items():
             buf = mail[(q, r)]
             off = 0
