@@ -366,6 +366,13 @@ def _bench(args, ctx, seq, plan, dev, rank, world, n_kf, W, H, voxel, t_dist, fo
         rows = [None] * world
         dist.all_gather_object(rows, mine)
         out["per_rank"] = rows
+        # what DESIGN.md section 6 predicts for this plan (C3 costs per keyframe, scaled by the keyframe's pixels): the
+        # time the last rank is done, without hand-overs and exchange -- to be held against ms_per_step and per_rank
+        blocks = [r["keyframes"] for r in rows]
+        scale = (W * H) / 921600.0
+        out["model"] = {"cost_us_per_c3_keyframe": list(dist_fusion.PIPELINE_COST),
+                        "last_rank_done_ms": dist_fusion.modelled_makespan([b / max(1, n_kf) for b in blocks],
+                                                                          dist_fusion.PIPELINE_COST, n_kf) * scale / 1e3}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, min(args.cpu_sample_frames, n_kf), W, H, voxel, t_dist)
     if rank == 0:

@@ -62,6 +62,7 @@ def test_two_rank_rehearsal_line(fusion_path):
     for r in pr:
         for k in ("phase_a_ms", "wait_ms", "phase_b_ms", "run_ms", "chain_host_ms", "mask_send_ms", "finish_ms", "exchange_ms"):
             assert r[k] >= 0.0, (k, r)
+    assert j["model"]["last_rank_done_ms"] > 0.0 and len(j["model"]["cost_us_per_c3_keyframe"]) == 4
     assert pr[0]["phase_a_ms"] == 0.0 and pr[1]["phase_a_ms"] > 0.0      # rank 0 runs the fused chain, rank 1 the two phases
     assert pr[0]["phase_b_ms"] > 0.0 and pr[1]["phase_b_ms"] > 0.0 and pr[1]["wait_ms"] > 0.0
     # the same sequence on one rank: the split must not change the cloud
