@@ -55,6 +55,10 @@
 #ifndef SFM_ACC_DEFER_FAR_MARKS
 #define SFM_ACC_DEFER_FAR_MARKS 0
 #endif
+// (Measured and removed, profiles/r03_ab_accept_chain.txt exp25: every mark has the scalar load of its mask pointer and a
+// wait for it in front of it -- the stores are `asm volatile` with a memory clobber, behind which the compiler reads
+// everything again.  With the four pointers read once per keyframe, ahead of the barrier, nothing changes: C3 18.1-18.2
+// against 18.1-18.3 ms, C2 2.79 against 2.74.  The scalar cache serves them; the wait is the marks' round trip.)
 #ifndef SFM_TABLE_DEDUP
 #define SFM_TABLE_DEDUP 1
 #endif
@@ -1920,7 +1924,8 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                 for (int j = 0; j < kAccIter; j++)
 #pragma unroll
                     for (int q = 0; q < kNearSlots; q++)
-                        if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit) mask_store_coherent(later_mask[q] + h[j][q]);
+                        if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit)
+                            mask_store_coherent(later_mask[q] + h[j][q]);
 #if !SFM_ACC_DEFER_FAR_MARKS
                 // ... the others four at a time (unconditional loads: a lane without an accepted pixel reads element 0)
                 for (uint32_t s0 = 4; s0 < nl; s0 += 4) {
@@ -1980,7 +1985,8 @@ __device__ __forceinline__ void accept_chain_body(const FrameDev *__restrict__ f
                 for (int j = 0; j < kAccIter; j++)
 #pragma unroll
                     for (int q = kNearSlots; q < 4; q++)
-                        if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit) mask_store_coherent(later_mask[q] + h[j][q]);
+                        if (acc[j] && (uint32_t)q < nl && h[j][q] != kNoHit)
+                            mask_store_coherent(later_mask[q] + h[j][q]);
                 for (uint32_t s0 = 4; s0 < nl; s0 += 4) {  // more than four later neighbours: four at a time
                     uint32_t h2[kAccIter][4];
 #pragma unroll
