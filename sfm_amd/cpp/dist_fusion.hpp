@@ -38,7 +38,7 @@ struct RankPlan {
 struct SplitCost {
     // microseconds per C3 keyframe on one MI355X: fused chain, phase A, phase B -- both chains as
     // sfm_fusion_run_chain runs them, the voxel filter behind the chain -- and that voxel filter alone on the device
-    double fused = 34.5, verdict = 42.4, accept = 9.1, filter = 9.3;
+    double fused = 34.6, verdict = 44.5, accept = 9.3, filter = 9.3;
     bool equal_blocks = false;
 };
 

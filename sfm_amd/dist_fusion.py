@@ -67,7 +67,7 @@ def shard_components(nbrs: Sequence[Sequence[int]], weights: Sequence[int], worl
 # later ranks -- both chains as sfm_fusion_run_chain runs them, the voxel filter behind the chain and not under it --
 # and that voxel filter (table + finalize kernels alone on the device).  Only the ratios matter, and only for speed:
 # any split is exact.
-PIPELINE_COST = (34.5, 42.4, 9.1, 9.3)
+PIPELINE_COST = (34.6, 44.5, 9.3, 9.3)
 
 
 def modelled_makespan(shares, cost=PIPELINE_COST, units: float = 1.0) -> float:

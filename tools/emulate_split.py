@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""What the block plan of a sequence split costs, block by block, MEASURED on one GPU: the ranks of an N-rank split of
+the bench workload are played one after the other on this GPU, each exactly as its rank would run (rank 0 the fused
+chain, the others phase A + phase B, ranks with successors through sfm_fusion_run_chain / export / sfm_fusion_finish),
+every rank's phase A, chain and voxel filter timed by the library's own events.  The per-rank times then go through
+the pipeline of DESIGN.md section 6 -- a rank starts chaining when its predecessor has stopped AND its own phase A is
+done, its voxel filter runs behind its chain -- which gives the time the last rank would be done if the ranks ran
+side by side.  Not a multi-GPU measurement: no transfer, no contention, one device; it checks the model's compute terms
+(cost proportional to keyframes, block-boundary effects) against the kernels.  Also checks that the blocks' clouds add
+up to the single run's point count.     usage (GPU box): python3 tools/emulate_split.py [--workload W] [--worlds 2,4,8]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import bench
+from sfm_amd import dist_fusion, fusion, synth
+
+
+def play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, reps):
+    probe = synth.make_sequence(n_kf, W, H, K=K, device="cpu", seed=20240315, components=1, radius_m=0.8, only=(0, 0),
+                                corridor_step_m=walk)
+    plans = dist_fusion.plan_sequence(probe.nbrs, [W * H] * n_kf, world)
+    params = fusion.default_params(voxel_size=voxel, T_dist=t_dist)
+    px = W * H
+    mail, rows = {}, []
+    for r, plan in enumerate(plans):
+        lo, hi = (plan.frames[0], plan.frames[-1] + 1) if plan.frames else (0, 0)
+        seq = synth.make_sequence(n_kf, W, H, K=K, device=dev, seed=20240315, components=1, radius_m=0.8, only=(lo, hi),
+                                  corridor_step_m=walk)
+        ctx = fusion.FusionContext(params, dev.index or 0, torch.cuda.current_stream().cuda_stream)
+        for g in plan.frames:
+            ctx.add_keyframe_device(seq.depth[g - seq.first].data_ptr(), seq.bgr[g - seq.first].data_ptr(), W, H,
+                                    seq.K[g], seq.T_wk[g], seq.T_kw[g])
+        for g in range(plan.first, plan.end):
+            ctx.set_neighbors(plan.local[g], [plan.local[j] for j in seq.nbrs[g]])
+        ctx.set_active_range(*plan.active_local)
+        best = None
+        for rep in range(reps + 1):          # the first pass sizes the lists and tables (untimed)
+            ctx.clear_imported_masks()
+            if r > 0:
+                ctx.precompute()
+            for q, fr in plan.recvs.items():
+                buf, off = mail[(q, r)], 0
+                for first, count in dist_fusion._runs([plan.local[g] for g in fr]):
+                    ctx.import_masks(first, count, buf.data_ptr() + off, count * px)
+                    off += count * px
+            if plan.sends:
+                ctx.run_chain()
+                for t, fr in plan.sends.items():
+                    buf = torch.empty(max(1, len(fr) * px), dtype=torch.uint8, device=dev)
+                    off = 0
+                    for first, count in dist_fusion._runs([plan.local[g] for g in fr]):
+                        ctx.export_masks(first, count, buf.data_ptr() + off, count * px)
+                        off += count * px
+                    mail[(r, t)] = buf
+                ctx.finish()
+            else:
+                ctx.run()
+            st = ctx.stats()
+            row = {"rank": r, "keyframes": plan.end - plan.first, "phase_a_ms": st["precompute_ms"],
+                   "chain_ms": st["frame_kernels_ms"], "run_ms": st["last_run_ms"]}
+            if rep and (best is None or row["run_ms"] + row["phase_a_ms"] < best["run_ms"] + best["phase_a_ms"]):
+                best = row
+        best["n_vox_local"] = st["n_vox"]
+        rows.append(best)
+        ctx.close()
+        del seq
+        torch.cuda.empty_cache()
+    # the pipeline: chains one after the other, a rank's chain not before its own phase A; the voxel filter of a rank
+    # with successors runs behind its chain (run_ms - chain_ms), the last rank's beside it (its run_ms is the whole)
+    end = done = 0.0
+    for i, row in enumerate(rows):
+        start = max(end, row["phase_a_ms"])
+        end = start + row["chain_ms"]
+        done = max(done, start + row["run_ms"])
+        row["chain_starts_at_ms"], row["chain_ends_at_ms"] = start, end
+        row["waits_for_own_phase_a_ms"] = max(0.0, row["phase_a_ms"] - (rows[i - 1]["chain_ends_at_ms"] if i else 0.0))
+    shares = [row["keyframes"] / n_kf for row in rows]
+    model = dist_fusion.modelled_makespan(shares, dist_fusion.PIPELINE_COST, n_kf) * (px / 921600.0) / 1e3
+    return {"world": world, "last_rank_done_ms": done, "chain_ends_ms": end, "model_last_rank_done_ms": model if world > 1 else None,
+            "ranks": rows}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c3_2000kf_1280x720_1cm", choices=sorted(bench.WORKLOADS))
+    ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--reps", type=int, default=2)
+    args = ap.parse_args()
+    n_kf, W, H, K, voxel, t_dist = bench.WORKLOADS[args.workload]
+    walk = bench.CORRIDOR.get(args.workload, 0.0)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    out = {"workload": args.workload, "note": "ranks played one after the other on ONE GPU; times from the library's events; "
+           "no transfers, no contention: a check of the model's compute terms, not a scaling measurement", "worlds": []}
+    single = None
+    for world in [int(x) for x in args.worlds.split(",")]:
+        res = play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, args.reps)
+        if world == 1:
+            single = res["last_rank_done_ms"]
+        res["speedup_over_one_gpu"] = single / res["last_rank_done_ms"] if single else None
+        out["worlds"].append(res)
+        print("world %d: last rank done %.2f ms (model %s), chain ends %.2f ms, x%.2f" % (
+            world, res["last_rank_done_ms"], "%.2f" % res["model_last_rank_done_ms"] if res["model_last_rank_done_ms"] else "-",
+            res["chain_ends_ms"], res["speedup_over_one_gpu"] or 1.0), file=sys.stderr, flush=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
