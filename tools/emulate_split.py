@@ -22,7 +22,7 @@ import bench
 from sfm_amd import dist_fusion, fusion, synth
 
 
-def play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, reps):
+def play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, reps, last_split=False):
     probe = synth.make_sequence(n_kf, W, H, K=K, device="cpu", seed=20240315, components=1, radius_m=0.8, only=(0, 0),
                                 corridor_step_m=walk)
     plans = dist_fusion.plan_sequence(probe.nbrs, [W * H] * n_kf, world)
@@ -50,7 +50,9 @@ def play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, reps):
                 for first, count in dist_fusion._runs([plan.local[g] for g in fr]):
                     ctx.import_masks(first, count, buf.data_ptr() + off, count * px)
                     off += count * px
-            if plan.sends:
+            # (--last-split plays the last rank in two halves too, filter behind its chain: measured on C3, no better than
+            # sfm_fusion_run -- 38.2 against 37.0 ms at N = 4, 26.4 against 26.5 at N = 8 -- so SequenceSplit does not)
+            if plan.sends or (r > 0 and last_split):
                 ctx.run_chain()
                 for t, fr in plan.sends.items():
                     buf = torch.empty(max(1, len(fr) * px), dtype=torch.uint8, device=dev)
@@ -92,6 +94,7 @@ def main():
     ap.add_argument("--workload", default="c3_2000kf_1280x720_1cm", choices=sorted(bench.WORKLOADS))
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--last-split", action="store_true", help="the last rank runs in two halves too (filter behind its chain)")
     args = ap.parse_args()
     n_kf, W, H, K, voxel, t_dist = bench.WORKLOADS[args.workload]
     walk = bench.CORRIDOR.get(args.workload, 0.0)
@@ -101,7 +104,7 @@ def main():
            "no transfers, no contention: a check of the model's compute terms, not a scaling measurement", "worlds": []}
     single = None
     for world in [int(x) for x in args.worlds.split(",")]:
-        res = play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, args.reps)
+        res = play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, args.reps, args.last_split)
         if world == 1:
             single = res["last_rank_done_ms"]
         res["speedup_over_one_gpu"] = single / res["last_rank_done_ms"] if single else None
