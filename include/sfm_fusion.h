@@ -236,6 +236,10 @@ int sfm_fusion_precompute(sfm_fusion_ctx *ctx);
 /* ORs masks into the state the next runs start from: keyframes [first, first+count), W*H bytes each, packed back
  * to back, device memory.  Dropped by set_active_range, add_keyframe, set_neighbors and clear_imported_masks. */
 int sfm_fusion_import_masks(sfm_fusion_ctx *ctx, uint32_t first, uint32_t count, const void *src_dev, uint64_t bytes);
+/* Drops the imports.  It also zeroes the mask arena right away (asynchronously, where the layout stands): the next run
+ * then starts from that arena as it is, and the imports made in between go straight into it -- a rank that calls this
+ * before it starts waiting has nothing but the imports themselves between its predecessors' masks and its chain.
+ * Imports still last until the next clear: a second run without one starts from the same masks. */
 int sfm_fusion_clear_imported_masks(sfm_fusion_ctx *ctx);
 /* After sfm_fusion_run (or sfm_fusion_run_chain): the masks of keyframes [first, first+count) as the run left them,
  * same packing. */

@@ -197,8 +197,14 @@ struct sfm_fusion_ctx {
     bool key_scan = false;             // the attempt at hand is a range-scan run
     uint32_t act_first = 0, act_end = 0xFFFFFFFFu;
     std::vector<uint64_t> mask_off;    // per keyframe: offset of its mask in d_masks
+    // d_mask_seed has the arena's layout, but only the keyframes named in seed_frames hold anything (never zeroed as a
+    // whole): the first import of a keyframe copies, later ones OR.  masks_ready: the mask arena itself is already what
+    // the next run starts from -- zeroed ahead of time by sfm_fusion_clear_imported_masks, the imports ORed in as they
+    // came -- so that nothing but the imports stands between a predecessor's masks and this rank's chain.
     DevBuf<uint8_t> d_mask_seed;
+    std::vector<uint32_t> seed_frames;
     bool have_seed = false;
+    bool masks_ready = false;
     // two-phase chain (sfm_fusion_precompute): the mask-independent verdicts of the active keyframes
     std::vector<uint32_t> h_nbr;       // filtered neighbours of every keyframe, back to back (FrameDev::nbr_begin)
     DevBuf<unsigned char> d_verdict_arena;
@@ -439,6 +445,8 @@ int build_layout(sfm_fusion_ctx *c)
     std::vector<uint64_t> &moff = c->mask_off;
     moff.assign(n, 0);
     c->have_seed = false;  // offsets may move: imported masks belong to the layout they were imported into
+    c->seed_frames.clear();
+    c->masks_ready = false;
     for (size_t i = 0; i < n; i++) {
         moff[i] = total;
         total += ((uint64_t)c->frames[i].W * c->frames[i].H + 255) / 256 * 256;
@@ -624,10 +632,17 @@ int run_launch(sfm_fusion_ctx *c, uint64_t table_cap, uint64_t shard_cap, uint64
         }
     hipStream_t sa = c->stream, sb = c->stream_b;
     HIP_TRY(c, hipEventRecord(c->ev[0], sa));
-    if (c->d_masks.n && c->have_seed)  // the masks the earlier blocks of the sequence left
-        HIP_TRY(c, hipMemcpyAsync(c->d_masks.p, c->d_mask_seed.p, c->d_masks.n, hipMemcpyDeviceToDevice, sa));
-    else if (c->d_masks.n)
+    if (c->masks_ready) {
+        // zeros (:40-45) and the masks the earlier blocks of the sequence left are in already: made ahead of the run
+        c->masks_ready = false;
+    } else if (c->d_masks.n) {
         HIP_TRY(c, hipMemsetAsync(c->d_masks.p, 0, c->d_masks.n, sa));  // :40-45
+        for (uint32_t i : c->seed_frames) {  // a run repeated on the same imports, or an attempt repeated
+            const uint64_t px = (uint64_t)c->frames[i].W * c->frames[i].H;
+            HIP_TRY(c, hipMemcpyAsync(c->d_masks.p + c->mask_off[i], c->d_mask_seed.p + c->mask_off[i], px,
+                                      hipMemcpyDeviceToDevice, sa));
+        }
+    }
     // the table is first touched by the first group's table kernel: its fill runs on stream B, under the first chain launch
     HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0xFF, table_cap * sizeof(Slot), sb));
     HIP_TRY(c, hipMemsetAsync(c->d_small, 0, kSmallZeroBytes, sa));
@@ -1666,8 +1681,8 @@ int sfm_fusion_import_masks(sfm_fusion_ctx *c, uint32_t first, uint32_t count, c
     if (c->layout_dirty && (rc = build_layout(c))) return rc;
     hipStream_t s = c->stream;
     if (!c->have_seed) {
-        if ((rc = ensure(c, c->d_mask_seed, c->d_masks.n))) return rc;
-        if (c->d_masks.n) HIP_TRY(c, hipMemsetAsync(c->d_mask_seed.p, 0, c->d_masks.n, s));
+        if ((rc = ensure(c, c->d_mask_seed, c->d_masks.n))) return rc;  // (same size for the life of a layout: made once)
+        c->seed_frames.clear();
         c->have_seed = true;
     }
     const uint8_t *src = static_cast<const uint8_t *>(src_dev);
@@ -1675,7 +1690,14 @@ int sfm_fusion_import_masks(sfm_fusion_ctx *c, uint32_t first, uint32_t count, c
         const uint64_t px = (uint64_t)c->frames[i].W * c->frames[i].H;
         if (!px) continue;
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((px + 1023) / 1024, 2048);
-        hipLaunchKernelGGL(mask_or_kernel, dim3(blocks), dim3(256), 0, s, c->d_mask_seed.p + c->mask_off[i], src, px);
+        if (std::find(c->seed_frames.begin(), c->seed_frames.end(), i) == c->seed_frames.end()) {
+            c->seed_frames.push_back(i);  // the keyframe's first import: its part of the seed holds nothing yet
+            HIP_TRY(c, hipMemcpyAsync(c->d_mask_seed.p + c->mask_off[i], src, px, hipMemcpyDeviceToDevice, s));
+        } else {
+            hipLaunchKernelGGL(mask_or_kernel, dim3(blocks), dim3(256), 0, s, c->d_mask_seed.p + c->mask_off[i], src, px);
+        }
+        if (c->masks_ready)  // ... and straight into the arena the next run starts from
+            hipLaunchKernelGGL(mask_or_kernel, dim3(blocks), dim3(256), 0, s, c->d_masks.p + c->mask_off[i], src, px);
         src += px;
     }
     HIP_TRY(c, hipGetLastError());
@@ -1689,7 +1711,17 @@ int sfm_fusion_clear_imported_masks(sfm_fusion_ctx *c)
     if (!c) return SFM_E_INVALID;
     if (c->rs.launched) return run_in_flight(c);
     c->have_seed = false;
+    c->seed_frames.clear();
     c->have_result = c->have_masks = false;
+    // The next run starts from zeros (plus what is imported from here on): zero the arena NOW, asynchronously -- a rank
+    // of a sequence split calls this before it starts waiting for its predecessors, and the 0.1-0.4 ms that the memset
+    // (and, before round 3, a copy of a whole seed arena) took stood between their masks' arrival and its chain.
+    c->masks_ready = false;
+    if (!c->layout_dirty && c->d_masks.n) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipMemsetAsync(c->d_masks.p, 0, c->d_masks.n, c->stream));
+        c->masks_ready = true;
+    }
     return SFM_OK;
 }
 

@@ -246,3 +246,56 @@ def test_a_chain_that_cannot_hold_its_barrier_falls_back_inside_the_first_half(f
     assert np.array_equal(xyz.view(np.uint64), want.xyz.view(np.uint64))
     assert ctx.stats()["chain_fallbacks"] == 1 and ctx.stats()["fused_chain"] == 0
     ctx.close()
+
+
+def test_imports_made_after_a_clear_go_straight_into_the_arena_and_still_last():
+    """sfm_fusion_clear_imported_masks zeroes the mask arena ahead of the run and the imports that follow go straight
+    into it (nothing but the imports between a predecessor's masks and the chain); the imports must still hold for a
+    SECOND run without another clear, for a keyframe imported twice (ORed), and be gone after the next clear."""
+    import torch
+    W, H = 48, 36
+    seq = synth.make_sequence(6, W, H, K=(98.4, 98.4, 23.5, 17.5), window=2)
+    frames = seq.frame_dicts()
+    _, gp = both_params(voxel_size=30.0, T_dist=500.0)
+    ctx = fusion.FusionContext(gp)
+    for f in frames:
+        ctx.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+    for i, f in enumerate(frames):
+        ctx.set_neighbors(i, f["nbrs"])
+    ctx.run()                                   # builds the layout; the clear below can zero ahead
+    plain = ctx.frame_counts()[0].copy()
+    assert plain[2] > 0 and plain[3] > 0
+    left = torch.zeros(H, W, dtype=torch.uint8, device="cuda")
+    left[:, : W // 2] = 255
+    right = torch.zeros(H, W, dtype=torch.uint8, device="cuda")
+    right[:, W // 2:] = 255
+    ctx.clear_imported_masks()
+    ctx.import_masks(2, 1, left.data_ptr(), W * H)      # keyframe 2: left half ...
+    ctx.import_masks(3, 1, left.data_ptr(), W * H)
+    ctx.import_masks(2, 1, right.data_ptr(), W * H)     # ... and right half: fully masked
+    for _ in range(2):                                   # the second run starts from the same imports
+        ctx.run()
+        got = ctx.frame_counts()[0]
+        assert got[2] == 0 and 0 < got[3] < plain[3]
+        m = torch.empty(2 * W * H, dtype=torch.uint8, device="cuda")
+        ctx.export_masks(2, 2, m.data_ptr(), 2 * W * H)
+        m = m.cpu().numpy().reshape(2, H, W)
+        assert m[0].all() and m[1][:, : W // 2].all()
+    half = ctx.frame_counts()[0].copy()
+    ctx.clear_imported_masks()
+    ctx.run()
+    assert np.array_equal(ctx.frame_counts()[0], plain)
+    # the same imports on a fresh ctx that has never run (no arena to zero ahead at the clear): same counts
+    ctx2 = fusion.FusionContext(gp)
+    for f in frames:
+        ctx2.add_keyframe(f["depth"], f["bgr"], f["K"], f["T_wk"], f["T_kw"])
+    for i, f in enumerate(frames):
+        ctx2.set_neighbors(i, f["nbrs"])
+    ctx2.clear_imported_masks()
+    ctx2.import_masks(2, 1, left.data_ptr(), W * H)
+    ctx2.import_masks(3, 1, left.data_ptr(), W * H)
+    ctx2.import_masks(2, 1, right.data_ptr(), W * H)
+    ctx2.run()
+    assert np.array_equal(ctx2.frame_counts()[0], half)
+    ctx.close()
+    ctx2.close()

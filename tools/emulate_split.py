@@ -12,6 +12,7 @@ import argparse
 import json
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -45,15 +46,19 @@ def play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, reps, last_split=False)
             ctx.clear_imported_masks()
             if r > 0:
                 ctx.precompute()
+            torch.cuda.synchronize()       # (phase A done: what follows stands between the masks' arrival and the chain)
+            t_imp = time.perf_counter()
             for q, fr in plan.recvs.items():
                 buf, off = mail[(q, r)], 0
                 for first, count in dist_fusion._runs([plan.local[g] for g in fr]):
                     ctx.import_masks(first, count, buf.data_ptr() + off, count * px)
                     off += count * px
+            t_run = time.perf_counter()
             # (--last-split plays the last rank in two halves too, filter behind its chain: measured on C3, no better than
             # sfm_fusion_run -- 38.2 against 37.0 ms at N = 4, 26.4 against 26.5 at N = 8 -- so SequenceSplit does not)
             if plan.sends or (r > 0 and last_split):
                 ctx.run_chain()
+                t_chain = time.perf_counter()
                 for t, fr in plan.sends.items():
                     buf = torch.empty(max(1, len(fr) * px), dtype=torch.uint8, device=dev)
                     off = 0
@@ -61,12 +66,18 @@ def play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, reps, last_split=False)
                         ctx.export_masks(first, count, buf.data_ptr() + off, count * px)
                         off += count * px
                     mail[(r, t)] = buf
+                t_exp = time.perf_counter()
                 ctx.finish()
             else:
                 ctx.run()
+                t_chain = t_exp = time.perf_counter()
             st = ctx.stats()
             row = {"rank": r, "keyframes": plan.end - plan.first, "phase_a_ms": st["precompute_ms"],
-                   "chain_ms": st["frame_kernels_ms"], "run_ms": st["last_run_ms"]}
+                   "chain_ms": st["frame_kernels_ms"], "run_ms": st["last_run_ms"],
+                   # host clocks: importing the predecessors' masks; from the run call to the masks final, less the chain
+                   # itself (what the run does in front of its chain); exporting the successors' masks
+                   "import_host_ms": (t_run - t_imp) * 1e3, "before_chain_host_ms": (t_chain - t_run) * 1e3 - st["frame_kernels_ms"],
+                   "export_host_ms": (t_exp - t_chain) * 1e3}
             if rep and (best is None or row["run_ms"] + row["phase_a_ms"] < best["run_ms"] + best["phase_a_ms"]):
                 best = row
         best["n_vox_local"] = st["n_vox"]
