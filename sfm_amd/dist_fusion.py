@@ -114,13 +114,14 @@ def block_shares(world: int, cost=PIPELINE_COST) -> list:
     return shares
 
 
-def split_blocks(weights: Sequence[int], world: int, cost=None) -> list:
+def split_blocks(weights: Sequence[int], world: int, cost=None, shares=None) -> list:
     """Cuts keyframes 0..n-1 into `world` contiguous blocks whose weights (pixels) follow block_shares(world, cost)
-    (cost=None: about equal weight).  Returns [(first, end)] per rank; a rank may get an empty block when there are
-    fewer keyframes than ranks."""
+    (cost=None: about equal weight; shares: given outright, one per block, summing to 1).  Returns [(first, end)] per
+    rank; a rank may get an empty block when there are fewer keyframes than ranks."""
     n = len(weights)
     total = sum(weights)
-    shares = block_shares(world, cost)
+    if shares is None:
+        shares = block_shares(world, cost)
     cuts = [0]
     acc = 0
     i = 0
@@ -157,13 +158,13 @@ class RankPlan:
         return (self.local[self.first], self.local[self.end - 1] + 1)
 
 
-def plan_sequence(nbrs: Sequence[Sequence[int]], weights: Sequence[int], world: int, cost=PIPELINE_COST) -> list:
+def plan_sequence(nbrs: Sequence[Sequence[int]], weights: Sequence[int], world: int, cost=PIPELINE_COST, shares=None) -> list:
     """Exact split of one keyframe sequence over `world` ranks by contiguous blocks.  Keyframe i marks pixels in
     the masks of its LATER neighbours (earlier masks are never read again): rank q therefore sends rank r > q the
     masks of those keyframes of r's block that a keyframe of q's block names as a neighbour.  Every rank computes
     the same plan from the same graph.  Block sizes follow block_shares(world, cost): small first blocks, so that
     the chain reaches the later ranks when their verdicts are ready (cost=None: equal blocks)."""
-    blocks = split_blocks(weights, world, cost)
+    blocks = split_blocks(weights, world, cost, shares)
     owner = {}
     for r, (a, b) in enumerate(blocks):
         for g in range(a, b):

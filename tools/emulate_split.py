@@ -23,10 +23,26 @@ import bench
 from sfm_amd import dist_fusion, fusion, synth
 
 
-def play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, reps, last_split=False):
+def cyclic_blocks(n_kf, first, growth, biggest):
+    """Block sizes of a CYCLIC plan: more blocks than ranks, block k on rank k mod N, small blocks first (the chain must
+    reach a rank when its phase A is done), growing up to `biggest` keyframes."""
+    out, size = [], float(first)
+    while sum(out) < n_kf:
+        out.append(min(int(round(size)), n_kf - sum(out)))
+        size = min(size * growth, biggest)
+    return out
+
+
+def play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, reps, last_split=False, cyclic=None, handover_ms=0.3):
     probe = synth.make_sequence(n_kf, W, H, K=K, device="cpu", seed=20240315, components=1, radius_m=0.8, only=(0, 0),
                                 corridor_step_m=walk)
-    plans = dist_fusion.plan_sequence(probe.nbrs, [W * H] * n_kf, world)
+    ranks = world
+    if cyclic:   # every block its own ctx, played in chain order; the pipeline below deals block k to rank k mod ranks
+        sizes = cyclic_blocks(n_kf, *cyclic)
+        world = len(sizes)
+        plans = dist_fusion.plan_sequence(probe.nbrs, [W * H] * n_kf, world, shares=[s / n_kf for s in sizes])
+    else:
+        plans = dist_fusion.plan_sequence(probe.nbrs, [W * H] * n_kf, world)
     params = fusion.default_params(voxel_size=voxel, T_dist=t_dist)
     px = W * H
     mail, rows = {}, []
@@ -88,6 +104,22 @@ def play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, reps, last_split=False)
     # the pipeline: chains one after the other, a rank's chain not before its own phase A; the voxel filter of a rank
     # with successors runs behind its chain (run_ms - chain_ms), the last rank's beside it (its run_ms is the whole)
     end = done = 0.0
+    if cyclic:
+        # block k on rank k mod ranks: a rank starts the phase A of its next block when its chain has ended, works its
+        # voxel filters off while it waits for the chain (or at the end), and every boundary costs a hand-over
+        free, owed = [0.0] * ranks, [0.0] * ranks
+        for i, row in enumerate(rows):
+            r = i % ranks
+            a_end = free[r] + row["phase_a_ms"]
+            start = max(end + (handover_ms if i else 0.0), a_end)
+            owed[r] -= min(owed[r], max(0.0, start - a_end))
+            end = start + row["chain_ms"]
+            free[r] = end
+            owed[r] += row["run_ms"] - row["chain_ms"]
+            row["on_rank"], row["chain_starts_at_ms"], row["chain_ends_at_ms"] = r, start, end
+        done = max(free[r] + owed[r] for r in range(ranks))
+        return {"world": ranks, "blocks": len(rows), "cyclic": list(cyclic), "handover_ms": handover_ms, "last_rank_done_ms": done,
+                "chain_ends_ms": end, "model_last_rank_done_ms": None, "ranks": rows}
     for i, row in enumerate(rows):
         start = max(end, row["phase_a_ms"])
         end = start + row["chain_ms"]
@@ -106,6 +138,9 @@ def main():
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--last-split", action="store_true", help="the last rank runs in two halves too (filter behind its chain)")
+    ap.add_argument("--cyclic", default=None, help="first,growth,biggest: a cyclic plan (more blocks than ranks, block k on rank "
+                    "k mod N) with these block sizes, e.g. 30,1.3,200 -- what DESIGN.md section 6 names as the next step")
+    ap.add_argument("--handover-ms", type=float, default=0.3)
     args = ap.parse_args()
     n_kf, W, H, K, voxel, t_dist = bench.WORKLOADS[args.workload]
     walk = bench.CORRIDOR.get(args.workload, 0.0)
@@ -115,7 +150,8 @@ def main():
            "no transfers, no contention: a check of the model's compute terms, not a scaling measurement", "worlds": []}
     single = None
     for world in [int(x) for x in args.worlds.split(",")]:
-        res = play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, args.reps, args.last_split)
+        cyc = tuple(float(x) for x in args.cyclic.split(",")) if args.cyclic and world > 1 else None
+        res = play(world, n_kf, W, H, K, voxel, t_dist, walk, dev, args.reps, args.last_split, cyc, args.handover_ms)
         if world == 1:
             single = res["last_rank_done_ms"]
         res["speedup_over_one_gpu"] = single / res["last_rank_done_ms"] if single else None
